@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (ylaboratory/ALPINE v0.2.0) on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Runs only where ``/root/reference`` exists (the build
+container); the GPU box never sees the reference, it gets the ``.npz`` files this script
+writes into ``tests/golden/``.  Nothing of the reference's source is copied: the script
+imports it, feeds it seeded inputs and records inputs + outputs.
+
+Four third-party modules the reference imports at module level are absent from this image
+(``anndata``, ``scanpy``, ``kneed``, ``hyperopt``); none of them is touched by
+``fit(max_iter=<int>)`` / ``store_embeddings`` (only ``isinstance`` checks on
+``ad.AnnData``, main.py:307,392), so empty stand-in modules are registered first
+(SURVEY.md 8c recipe).
+
+Usage:  python oracle/gen_golden.py [--out tests/golden] [--only NAME ...]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+
+REFERENCE = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _install_stubs():
+    sys.dont_write_bytecode = True          # the reference tree is read-only
+    stubs = {
+        "scanpy": {},
+        "kneed": {"KneeLocator": object},
+        "hyperopt": dict(fmin=None, tpe=None, hp=None, Trials=None, STATUS_OK=None, STATUS_FAIL=None),
+    }
+    for name, attrs in stubs.items():
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    class AnnData:                           # minimal stand-in: only what fit/store_embeddings touch
+        def __init__(self, X, obs=None, var_names=None):
+            self.X = X
+            self.obs = obs
+            self.var_names = pd.Index(var_names if var_names is not None
+                                      else [f"gene{i}" for i in range(X.shape[1])])
+            self.shape = X.shape
+            self.obsm, self.varm, self.layers = {}, {}, {}
+
+    ad = types.ModuleType("anndata")
+    ad.AnnData = AnnData
+    sys.modules["anndata"] = ad
+    sys.path.insert(0, REFERENCE)
+    return AnnData
+
+
+# --------------------------------------------------------------------------- cases
+def _labels(rng, n, levels, nan_frac=0.0):
+    lab = rng.choice(levels, size=n).astype(object)
+    if nan_frac > 0:
+        lab[rng.random(n) < nan_frac] = np.nan
+    return lab
+
+
+def make_case_inputs(case: dict):
+    """Seeded inputs of a case: X (cells x genes, float32) and the obs columns."""
+    sys.path.insert(0, REPO)
+    from alpine_amd.datasets import synth_counts_host
+    rng = np.random.default_rng(case["seed"])
+    n, g = case["n_cells"], case["n_genes"]
+    if case.get("data", "gamma") == "gamma":
+        X = rng.gamma(0.3, 3.0, size=(n, g)).astype(np.float32)
+    else:
+        X = synth_counts_host(n, g, rank=case["params"]["n_components"], seed=case["seed"])
+    obs = {}
+    for key, levels, nan_frac in case["covariates"]:
+        obs[key] = _labels(rng, n, levels, nan_frac)
+    return X, pd.DataFrame(obs)
+
+
+CASES = [
+    dict(name="kl_1cov", n_cells=96, n_genes=64, seed=0, T=50,
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[1e3])),
+    dict(name="fro_1cov", n_cells=96, n_genes=64, seed=1, T=50,
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[10.0], loss_type="frobenius")),
+    dict(name="kl_reg", n_cells=96, n_genes=64, seed=2, T=50,
+         covariates=[("cond", ["ctl", "stim"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[1e3],
+                     orth_W=0.1, alpha_W=0.5, l1_ratio_W=0.3)),
+    dict(name="kl_2cov_nan", n_cells=120, n_genes=80, seed=3, T=30,
+         covariates=[("c1", ["x", "y", "z"], 0.1), ("c2", ["p", "q"], 0.05)],
+         params=dict(n_components=5, n_covariate_components=[2, 3], lam=[1e3, 5e2])),
+    dict(name="fro_2cov_reg", n_cells=120, n_genes=80, seed=4, T=30,
+         covariates=[("c1", ["x", "y", "z"], 0.1), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=5, n_covariate_components=[2, 3], lam=[5.0, 2.0],
+                     loss_type="frobenius", orth_W=0.05, alpha_W=0.2, l1_ratio_W=0.5)),
+    dict(name="ragged", n_cells=257, n_genes=130, seed=5, T=20,
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=7, n_covariate_components=[3], lam=[1e3])),
+    dict(name="one_iter", n_cells=96, n_genes=64, seed=6, T=1,
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[1e3])),
+    dict(name="k74", n_cells=300, n_genes=150, seed=7, T=10,
+         covariates=[("cond", ["a", "b", "c"], 0.0)],
+         params=dict(n_components=70, n_covariate_components=[4], lam=[1e3])),
+    dict(name="k105", n_cells=200, n_genes=160, seed=8, T=5,
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=100, n_covariate_components=[5], lam=[1e3])),
+    dict(name="counts_2cov", n_cells=400, n_genes=300, seed=9, T=40, data="counts",
+         covariates=[("cond", ["a", "b"], 0.0), ("batch", ["b0", "b1"], 0.0)],
+         params=dict(n_components=12, n_covariate_components=[3, 3], lam=[1e3, 1e3],
+                     alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5)),
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
+    # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
+    dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=20, n_covariate_components=[2], lam=[1e3])),
+]
+
+
+def _cat(mats_w, mats_h):
+    return (np.concatenate([np.asarray(w, dtype=np.float32) for w in mats_w], axis=1),
+            np.concatenate([np.asarray(h, dtype=np.float32) for h in mats_h], axis=0))
+
+
+def run_case(case: dict, AnnData, out_dir: str):
+    import alpine  # the reference
+    X, obs = make_case_inputs(case)
+    keys = [c[0] for c in case["covariates"]]
+    params = dict(case["params"])
+    out = {}
+
+    def run(T, scale):
+        a = AnnData(X.copy(), obs.copy())
+        m = alpine.ALPINE(device="cpu", scale_needed=scale, **params)
+        m.fit(a, covariate_keys=keys, max_iter=T)
+        return m, a
+
+    # init exactly as fit() produces it (main.py:135 -> :436-472)
+    m0 = alpine.ALPINE(device="cpu", **params)
+    m0.fe = alpine.main.FeatureEncoders(keys)
+    Y0 = m0.fe.fit_transform(obs)
+    mats = m0._initialize_matrices(np.ascontiguousarray(X.T), Y0)
+    out["W0"], out["H0"] = _cat([w.numpy() for w in mats.Ws], [h.numpy() for h in mats.Hs])
+    for i, b in enumerate(mats.Bs):
+        out[f"B0_{i}"] = b.numpy().astype(np.float32)
+
+    # one step, unscaled
+    m1, _ = run(1, False)
+    out["W1"], out["H1"] = _cat(m1.matrices["Ws"], m1.matrices["Hs"])
+    for i, b in enumerate(m1.matrices["Bs"]):
+        out[f"B1_{i}"] = b
+    # T steps, unscaled and scaled
+    mu, _ = run(case["T"], False)
+    out["WT_unscaled"], out["HT_unscaled"] = _cat(mu.matrices["Ws"], mu.matrices["Hs"])
+    for i, b in enumerate(mu.matrices["Bs"]):
+        out[f"BT_unscaled_{i}"] = b
+    ms, a_s = run(case["T"], True)
+    out["WT"], out["HT"] = _cat(ms.matrices["Ws"], ms.matrices["Hs"])
+    for i, b in enumerate(ms.matrices["Bs"]):
+        out[f"BT_{i}"] = b
+    for i, y in enumerate(ms.matrices["Ys"]):
+        out[f"Y_{i}"] = y                                   # C_i x N as the reference holds it
+    out["loss_history"] = ms.loss_history.to_numpy(dtype=np.float64)
+    assert np.array_equal(mu.loss_history.to_numpy(), ms.loss_history.to_numpy())
+
+    meta = dict(
+        name=case["name"], n_cells=case["n_cells"], n_genes=case["n_genes"], seed=case["seed"],
+        T=case["T"], data=case.get("data", "gamma"), covariate_keys=keys,
+        covariates=[[k, lv, nf] for k, lv, nf in case["covariates"]],
+        params=params, loss_columns=list(ms.loss_history.columns),
+        encoded_labels=ms.fe.encoded_labels,
+        obsm_shapes={k: list(np.asarray(v).shape) for k, v in a_s.obsm.items()},
+        varm_shapes={k: list(np.asarray(v).shape) for k, v in a_s.varm.items()},
+        x_sha256=hashlib.sha256(np.ascontiguousarray(X).tobytes()).hexdigest(),
+        generator="oracle/gen_golden.py running /root/reference (ALPINE v0.2.0) on torch-CPU",
+    )
+    import torch
+    meta["torch"] = torch.__version__
+    meta["torch_threads"] = torch.get_num_threads()
+    if case.get("store_X", True):
+        out["X"] = X
+        for k in keys:
+            out[f"obs_{k}"] = np.array(["__nan__" if (isinstance(v, float) and np.isnan(v)) else v
+                                        for v in obs[k].tolist()], dtype="U16")
+    out["meta_json"] = np.array(json.dumps(meta))
+    path = os.path.join(out_dir, f"{case['name']}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{case['name']:>14}: {os.path.getsize(path) / 1024:8.1f} KiB  "
+          f"loss[-1]={out['loss_history'][-1].tolist()}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    if not os.path.isdir(REFERENCE):
+        sys.exit("the reference is not present here; golden vectors can only be regenerated in the build container")
+    AnnData = _install_stubs()
+    os.makedirs(args.out, exist_ok=True)
+    for case in CASES:
+        if args.only and case["name"] not in args.only:
+            continue
+        run_case(case, AnnData, args.out)
+
+
+if __name__ == "__main__":
+    main()
