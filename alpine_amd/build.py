@@ -1,0 +1,41 @@
+"""Build libalpine_hip.so (gfx950 only) in-tree with hipcc.  Used by __graft_entry__.build()."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "alpine_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hpp"), os.path.join(os.path.dirname(HERE), "include", "alpine_hip.h")]
+LIB = os.path.join(HERE, "libalpine_hip.so")
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libalpine_hip.so cannot be built")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,723 @@
+// libalpine_hip.so -- C ABI (include/alpine_hip.h) over the gfx950 kernels in kernels.hpp.
+// Host side of one shard (one GPU) of ALPINE's full-batch MU fit loop (alpine/main.py:486-676).
+#include "../../include/alpine_hip.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace alpine;
+
+static thread_local std::string g_create_error;
+
+struct alpine_ctx {
+    // geometry
+    int G = 0, N = 0, K = 0, KP = 0, KT = 0, n_cov = 0;
+    int64_t Gp = 0, Np = 0;
+    std::vector<int> cov_k, cov_lev;
+    std::vector<double> lam;
+    double orth = 0, alpha = 0, l1r = 0, eps = 0;
+    int loss_type = 0;
+    CovMeta meta{};
+    int nstat = 0, nB = 0, nYrows = 0;
+    int device = 0, n_cu = 256;
+    // stream
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device buffers
+    float *Xgn = nullptr, *Xng = nullptr, *W = nullptr, *H = nullptr, *Y = nullptr, *B[2] = {nullptr, nullptr};
+    int bcur = 0;
+    float *slabA = nullptr, *slabB = nullptr;
+    int splitA = 1, splitB = 1, rpsA = 0, rpsB = 0, nftA = 0, nftB = 0, gridA = 0, gridB = 0;
+    float* red = nullptr;
+    bool own_red = false;
+    int64_t red_floats = 0, red_hht = 0, red_stats = 0;
+    float *WtW = nullptr, *gramPart = nullptr;
+    int gramBlocksH = 0, gramBlocksW = 0;
+    float* statPart = nullptr;
+    int statBlocks = 0;
+    int* kind = nullptr;
+    double *dotpart = nullptr, *lam_dev = nullptr, *loss_dev = nullptr, *f64part = nullptr;
+    int ndot = 0;
+    int64_t loss_cap = 0, loss_rows = 0, f64part_n = 0;
+    float* scale = nullptr;
+    float* stage = nullptr;           // staging for host uploads / factor packing
+    int64_t stage_floats = 0;
+    // state
+    double xnorm2 = 0;
+    std::vector<char> x_seen;         // coarse coverage tracking of uploaded cell chunks
+    int64_t x_cells_uploaded = 0;
+    bool x_final = false, factors_set = false, pending_loss = false, loss_enabled = true;
+    std::vector<bool> y_set;
+    size_t bytes = 0;
+    std::string err;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ALPINE_KERNEL_COUNT];
+    size_t ev_used[ALPINE_KERNEL_COUNT] = {0, 0};
+};
+
+static int fail(alpine_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), e_ == hipErrorOutOfMemory ? ALPINE_ERR_OOM : ALPINE_ERR_HIP,         \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define DISPATCH_KT(kt, CALL)                  \
+    switch (kt) {                              \
+        case 1: { constexpr int KT_ = 1; CALL; } break; \
+        case 2: { constexpr int KT_ = 2; CALL; } break; \
+        case 3: { constexpr int KT_ = 3; CALL; } break; \
+        default: { constexpr int KT_ = 4; CALL; } break; \
+    }
+
+static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+static int dev_alloc(alpine_ctx* c, void** p, size_t bytes, bool zero = true)
+{
+    if (bytes == 0) bytes = 16;
+    HIPCHK(c, hipMalloc(p, bytes));
+    c->bytes += bytes;
+    if (zero) HIPCHK(c, hipMemsetAsync(*p, 0, bytes, c->stream));
+    return 0;
+}
+#define ALLOC(c, ptr, T, count) \
+    do { int rc_ = dev_alloc((c), reinterpret_cast<void**>(&(ptr)), sizeof(T) * (size_t)(count)); if (rc_) return rc_; } while (0)
+
+// ---------------------------------------------------------------------------------- geometry
+struct Geometry {
+    int K, KP, KT, nstat, nB, nYrows;
+    int64_t Gp, Np, red_floats, red_hht, red_stats;
+};
+
+static int geometry(const alpine_config* cfg, Geometry* g, std::string* why)
+{
+    if (!cfg || cfg->struct_size != (int32_t)sizeof(alpine_config)) { *why = "alpine_config.struct_size mismatch"; return -1; }
+    if (cfg->n_genes <= 0 || cfg->n_cells <= 0) { *why = "n_genes and n_cells must be positive"; return -1; }
+    if (cfg->n_genes > (1 << 30) || cfg->n_cells > (1 << 30)) { *why = "n_genes / n_cells too large for this build"; return -1; }
+    if (cfg->n_components <= 0) { *why = "n_components must be greater than 0."; return -1; }
+    if (cfg->n_covariates < 0 || cfg->n_covariates > MAX_COV) { *why = "n_covariates out of range (0..16)"; return -1; }
+    if (cfg->n_covariates > 0 && (!cfg->cov_components || !cfg->cov_levels || !cfg->lam)) { *why = "covariate arrays are NULL"; return -1; }
+    int K = cfg->n_components, guided = 0, nstat = 0, nB = 0, nY = 0;
+    for (int i = 0; i < cfg->n_covariates; ++i) {
+        const int k = cfg->cov_components[i], C = cfg->cov_levels[i];
+        if (k <= 0 || k > MAX_COV_K) { *why = "each covariate needs 1..64 guided components in this build"; return -1; }
+        if (C <= 0) { *why = "each covariate needs at least one level"; return -1; }
+        if (!(cfg->lam[i] >= 0)) { *why = "Each element in lam must be a non-negative float."; return -1; }
+        K += k; guided += k;
+        nstat += C * k + k + 2;
+        nB += C * k;
+        nY += C;
+    }
+    if (guided > 64) { *why = "the guided components must fit in the first 64 columns (sum k_i <= 64)"; return -1; }
+    if (K > 128) { *why = "total components > 128 not supported by this build"; return -1; }
+    if (cfg->loss_type != ALPINE_LOSS_KL && cfg->loss_type != ALPINE_LOSS_FROBENIUS) { *why = "loss_type must be one of ['kl-divergence', 'frobenius']."; return -1; }
+    if (!(cfg->eps >= 0) || !(cfg->alpha_W >= 0) || !(cfg->orth_W >= 0) || !(cfg->l1_ratio_W >= 0 && cfg->l1_ratio_W <= 1)) { *why = "eps/alpha_W/orth_W must be >= 0 and l1_ratio_W in [0,1]"; return -1; }
+    g->K = K;
+    g->KT = (K + 31) / 32;
+    g->KP = 32 * g->KT;
+    g->nstat = nstat; g->nB = nB; g->nYrows = nY;
+    g->Gp = round_up(cfg->n_genes, 128);
+    g->Np = round_up(cfg->n_cells, 128);
+    g->red_hht = g->Gp * g->KP;
+    g->red_stats = g->red_hht + (int64_t)g->KP * g->KP;
+    g->red_floats = round_up(g->red_stats + nstat + 2, 4);
+    return 0;
+}
+
+extern "C" int64_t alpine_reduce_block_floats(const alpine_config* cfg)
+{
+    Geometry g; std::string why;
+    if (geometry(cfg, &g, &why)) { g_create_error = why; return ALPINE_ERR_BAD_ARG; }
+    return g.red_floats;
+}
+
+// Number of partial slabs for a sweep: trade the tail of the last round of workgroups against
+// the extra slab traffic (2 * s * KP / R of the streamed bytes).
+static int choose_split(int n_ftiles, int64_t R, int KP, int slots, int forced)
+{
+    if (forced > 0) return (int)std::min<int64_t>(forced, std::max<int64_t>(1, R / SG_CH));
+    double best = 1e30; int best_s = 1;
+    for (int s = 1; s <= 96; ++s) {
+        if (R / s < 512 && s > 1) break;
+        const double rounds = (double)n_ftiles * s / slots;
+        const double tail = std::ceil(rounds - 1e-9) / rounds;
+        const double cost = tail * (1.0 + 2.0 * s * KP / (double)R);
+        if (cost < best - 1e-9) { best = cost; best_s = s; }
+    }
+    return best_s;
+}
+
+// ---------------------------------------------------------------------------------- create
+static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& g)
+{
+    c->G = (int)cfg->n_genes; c->N = (int)cfg->n_cells;
+    c->K = g.K; c->KP = g.KP; c->KT = g.KT; c->Gp = g.Gp; c->Np = g.Np;
+    c->n_cov = cfg->n_covariates;
+    c->nstat = g.nstat; c->nB = g.nB; c->nYrows = g.nYrows;
+    c->orth = cfg->orth_W; c->alpha = cfg->alpha_W; c->l1r = cfg->l1_ratio_W; c->eps = cfg->eps;
+    c->loss_type = cfg->loss_type;
+    c->device = cfg->device_id;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(c, ALPINE_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
+    c->n_cu = prop.multiProcessorCount;
+    if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+    else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+
+    // covariate metadata
+    c->meta.n_cov = c->n_cov; c->meta.loss_type = c->loss_type;
+    int off = 0, boff = 0, yoff = 0, soff = 0;
+    std::vector<int> kind(std::max(1, c->nstat), 0);
+    for (int i = 0; i < c->n_cov; ++i) {
+        const int k = cfg->cov_components[i], C = cfg->cov_levels[i];
+        c->cov_k.push_back(k); c->cov_lev.push_back(C); c->lam.push_back(cfg->lam[i]);
+        c->meta.off[i] = off; c->meta.k[i] = k; c->meta.lev[i] = C;
+        c->meta.boff[i] = boff; c->meta.yoff[i] = yoff; c->meta.soff[i] = soff;
+        c->meta.lam[i] = (float)cfg->lam[i]; c->meta.lam2[i] = (float)(2.0 * cfg->lam[i]);
+        kind[soff + C * k + k] = 1; kind[soff + C * k + k + 1] = 2;
+        off += k; boff += C * k; yoff += C; soff += C * k + k + 2;
+    }
+    c->y_set.assign(c->n_cov, false);
+
+    const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
+    // sweeps
+    const int slots = c->n_cu * (c->KT <= 2 ? 2 : 1);
+    c->nftA = (int)((Gp + SG_BLOCK_F - 1) / SG_BLOCK_F);      // XH^T: f = genes, r = cells
+    c->nftB = (int)((Np + SG_BLOCK_F - 1) / SG_BLOCK_F);      // W^TX: f = cells, r = genes
+    int sA = choose_split(c->nftA, Np, KP, slots, cfg->split_a);
+    int sB = choose_split(c->nftB, Gp, KP, slots, cfg->split_b);
+    c->rpsA = (int)round_up((Np + sA - 1) / sA, SG_CH); c->splitA = (int)((Np + c->rpsA - 1) / c->rpsA);
+    c->rpsB = (int)round_up((Gp + sB - 1) / sB, SG_CH); c->splitB = (int)((Gp + c->rpsB - 1) / c->rpsB);
+    c->gridA = c->nftA * c->splitA; c->gridB = c->nftB * c->splitB;
+
+    ALLOC(c, c->Xgn, float, Gp * Np);
+    ALLOC(c, c->Xng, float, Np * Gp);
+    ALLOC(c, c->W, float, Gp * KP);
+    ALLOC(c, c->H, float, Np * KP);
+    ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
+    ALLOC(c, c->B[0], float, std::max(1, c->nB));
+    ALLOC(c, c->B[1], float, std::max(1, c->nB));
+    ALLOC(c, c->slabA, float, (int64_t)c->splitA * Gp * KP);
+    ALLOC(c, c->slabB, float, (int64_t)c->splitB * Np * KP);
+    c->red_floats = g.red_floats; c->red_hht = g.red_hht; c->red_stats = g.red_stats;
+    if (cfg->reduce_block) { c->red = (float*)cfg->reduce_block; c->own_red = false; HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream)); }
+    else { ALLOC(c, c->red, float, c->red_floats); c->own_red = true; }
+    ALLOC(c, c->WtW, float, KP * KP);
+    const int rows_per_gram_block = 4 * GR_ROWS_PER_WAVE;
+    c->gramBlocksH = (int)((Np + rows_per_gram_block - 1) / rows_per_gram_block);
+    c->gramBlocksW = (int)((Gp + rows_per_gram_block - 1) / rows_per_gram_block);
+    ALLOC(c, c->gramPart, float, (int64_t)std::max(c->gramBlocksH, c->gramBlocksW) * 4 * KP * KP);
+    c->statBlocks = (int)((c->N + HS_CELLS - 1) / HS_CELLS);
+    ALLOC(c, c->statPart, float, (int64_t)c->statBlocks * std::max(1, c->nstat));
+    ALLOC(c, c->kind, int, kind.size());
+    HIPCHK(c, hipMemcpyAsync(c->kind, kind.data(), sizeof(int) * kind.size(), hipMemcpyHostToDevice, c->stream));
+    c->ndot = (int)((c->G + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4)) * 4;
+    ALLOC(c, c->dotpart, double, c->ndot);
+    ALLOC(c, c->lam_dev, double, std::max(1, c->n_cov));
+    if (c->n_cov) HIPCHK(c, hipMemcpyAsync(c->lam_dev, c->lam.data(), sizeof(double) * c->n_cov, hipMemcpyHostToDevice, c->stream));
+    c->loss_cap = 1024;
+    ALLOC(c, c->loss_dev, double, c->loss_cap * (c->n_cov + 2));
+    c->f64part_n = 65536;
+    ALLOC(c, c->f64part, double, c->f64part_n);
+    ALLOC(c, c->scale, float, KP);
+    c->stage_floats = std::max<int64_t>((int64_t)1 << 26, std::max<int64_t>((int64_t)c->K * Np, Gp * (int64_t)KP));   // >= 256 MiB
+    ALLOC(c, c->stage, float, c->stage_floats);
+    c->x_seen.assign((size_t)((c->N + 1023) / 1024), 0);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // kind[] / lam[] host vectors go out of scope
+    return 0;
+}
+
+extern "C" int alpine_create(const alpine_config* cfg, alpine_ctx** out)
+{
+    if (!out) return fail(nullptr, ALPINE_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    Geometry g; std::string why;
+    if (geometry(cfg, &g, &why)) return fail(nullptr, ALPINE_ERR_BAD_ARG, "%s", why.c_str());
+    alpine_ctx* c = new (std::nothrow) alpine_ctx();
+    if (!c) return fail(nullptr, ALPINE_ERR_OOM, "host allocation failed");
+    const int rc = create_impl(c, cfg, g);
+    if (rc) { g_create_error = c->err; alpine_destroy(c); return rc; }
+    *out = c;
+    return 0;
+}
+
+extern "C" int alpine_destroy(alpine_ctx* c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->slabA, c->slabB, c->own_red ? c->red : nullptr,
+                    c->WtW, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" const char* alpine_last_error(const alpine_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
+{
+    if (!c || !info) return fail(c, ALPINE_ERR_BAD_ARG, "NULL argument");
+    info->abi_version = ALPINE_HIP_ABI_VERSION;
+    info->k_total = c->K; info->k_padded = c->KP;
+    info->split_a = c->splitA; info->split_b = c->splitB; info->grid_a = c->gridA; info->grid_b = c->gridB;
+    info->genes_padded = c->Gp; info->cells_padded = c->Np;
+    info->reduce_block_floats = c->red_floats;
+    info->device_bytes = (int64_t)c->bytes;
+    info->x_sqnorm = c->xnorm2;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- ingest
+static int upload_x_dev(alpine_ctx* c, const float* dev, int layout, int64_t ld, int64_t cell0, int64_t n)
+{
+    const int G = c->G;
+    if (layout == ALPINE_X_CELLS_BY_GENES) {
+        HIPCHK(c, hipMemcpy2DAsync(c->Xng + cell0 * c->Gp, sizeof(float) * c->Gp, dev, sizeof(float) * ld,
+                                   sizeof(float) * G, (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        dim3 grid((G + 31) / 32, (unsigned)((n + 31) / 32));
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, dev, ld, c->Xgn + cell0, c->Np, (int)n, G);
+    } else {
+        HIPCHK(c, hipMemcpy2DAsync(c->Xgn + cell0, sizeof(float) * c->Np, dev, sizeof(float) * ld,
+                                   sizeof(float) * (size_t)n, (size_t)G, hipMemcpyDeviceToDevice, c->stream));
+        dim3 grid((unsigned)((n + 31) / 32), (G + 31) / 32);
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, dev, ld, c->Xng + cell0 * c->Gp, c->Gp, G, (int)n);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int check_x_args(alpine_ctx* c, const float* p, int layout, int64_t ld, int64_t cell0, int64_t n)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!p) return fail(c, ALPINE_ERR_BAD_ARG, "X pointer is NULL");
+    if (layout != ALPINE_X_CELLS_BY_GENES && layout != ALPINE_X_GENES_BY_CELLS) return fail(c, ALPINE_ERR_BAD_ARG, "unknown X layout %d", layout);
+    if (cell0 < 0 || n <= 0 || cell0 + n > c->N) return fail(c, ALPINE_ERR_BAD_ARG, "cell range [%lld, %lld) outside the shard's %d cells", (long long)cell0, (long long)(cell0 + n), c->N);
+    const int64_t min_ld = layout == ALPINE_X_CELLS_BY_GENES ? c->G : n;
+    if (ld < min_ld) return fail(c, ALPINE_ERR_BAD_ARG, "ld %lld smaller than the row length %lld", (long long)ld, (long long)min_ld);
+    return 0;
+}
+
+static void mark_x(alpine_ctx* c, int64_t n) { c->x_cells_uploaded += n; c->x_final = false; }
+
+extern "C" int alpine_upload_X_device(alpine_ctx* c, const float* dev, int layout, int64_t ld, int64_t cell0, int64_t n)
+{
+    int rc = check_x_args(c, dev, layout, ld, cell0, n);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = upload_x_dev(c, dev, layout, ld, cell0, n);
+    if (rc) return rc;
+    mark_x(c, n);
+    return 0;
+}
+
+extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout, int64_t ld, int64_t cell0, int64_t n)
+{
+    int rc = check_x_args(c, host, layout, ld, cell0, n);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int G = c->G;
+    if (layout == ALPINE_X_CELLS_BY_GENES) {
+        const int64_t step = std::max<int64_t>(1, c->stage_floats / G);
+        for (int64_t r = 0; r < n; r += step) {
+            const int64_t m = std::min(step, n - r);
+            HIPCHK(c, hipStreamSynchronize(c->stream));         // staging buffer is reused
+            HIPCHK(c, hipMemcpy2D(c->stage, sizeof(float) * G, host + r * ld, sizeof(float) * ld, sizeof(float) * G, (size_t)m, hipMemcpyHostToDevice));
+            rc = upload_x_dev(c, c->stage, layout, G, cell0 + r, m);
+            if (rc) return rc;
+        }
+    } else {
+        const int64_t step = std::max<int64_t>(1, c->stage_floats / G);      // cells per piece
+        for (int64_t r = 0; r < n; r += step) {
+            const int64_t m = std::min(step, n - r);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpy2D(c->stage, sizeof(float) * m, host + r, sizeof(float) * ld, sizeof(float) * m, (size_t)G, hipMemcpyHostToDevice));
+            rc = upload_x_dev(c, c->stage, layout, m, cell0 + r, m);
+            if (rc) return rc;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    mark_x(c, n);
+    return 0;
+}
+
+static int sum_f64_partials(alpine_ctx* c, int n, double* out)
+{
+    std::vector<double> h(n);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->f64part, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double s = 0;
+    for (double v : h) s += v;
+    *out = s;
+    return 0;
+}
+
+extern "C" int alpine_finalize_X(alpine_ctx* c)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (c->x_cells_uploaded < c->N) return fail(c, ALPINE_ERR_STATE, "only %lld of %d cells of X were uploaded", (long long)c->x_cells_uploaded, c->N);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n4 = c->Gp * c->Np / 4;
+    const int blocks = (int)std::min<int64_t>(4096, (n4 + 255) / 256);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn, n4, c->f64part);
+    HIPCHK(c, hipGetLastError());
+    int rc = sum_f64_partials(c, blocks, &c->xnorm2);
+    if (rc) return rc;
+    c->x_final = true;
+    return 0;
+}
+
+extern "C" int alpine_upload_Y(alpine_ctx* c, int cov, const float* host, int64_t ld)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (cov < 0 || cov >= c->n_cov) return fail(c, ALPINE_ERR_BAD_ARG, "covariate index %d out of range", cov);
+    if (!host || ld < c->N) return fail(c, ALPINE_ERR_BAD_ARG, "bad Y pointer / ld");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(c->Y + (int64_t)c->meta.yoff[cov] * c->Np, sizeof(float) * c->Np, host, sizeof(float) * ld,
+                          sizeof(float) * c->N, (size_t)c->cov_lev[cov], hipMemcpyHostToDevice));
+    c->y_set[cov] = true;
+    return 0;
+}
+
+extern "C" int alpine_set_factors(alpine_ctx* c, const float* W, const float* H, int64_t ldH, const float* const* B)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!W || !H || ldH < c->N || (c->n_cov > 0 && !B)) return fail(c, ALPINE_ERR_BAD_ARG, "bad factor pointers / ldH");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int K = c->K, KP = c->KP;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // W: G x K -> [Gp][KP]
+    HIPCHK(c, hipMemsetAsync(c->W, 0, sizeof(float) * c->Gp * KP, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage, W, sizeof(float) * (size_t)c->G * K, hipMemcpyHostToDevice, c->stream));
+    {
+        const int64_t n = (int64_t)c->G * K;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->stage, (int64_t)K, c->W, KP, (int64_t)c->G, K);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // H: K x N (ldH) -> [Np][KP] cell-major
+    HIPCHK(c, hipMemsetAsync(c->H, 0, sizeof(float) * c->Np * KP, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->stage, sizeof(float) * c->N, H, sizeof(float) * ldH, sizeof(float) * c->N, (size_t)K, hipMemcpyHostToDevice, c->stream));
+    {
+        dim3 grid((unsigned)((c->N + 31) / 32), (K + 31) / 32);
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->stage, (int64_t)c->N, c->H, (int64_t)KP, K, c->N);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bcur = 0;
+    for (int i = 0; i < c->n_cov; ++i) {
+        if (!B[i]) return fail(c, ALPINE_ERR_BAD_ARG, "B[%d] is NULL", i);
+        HIPCHK(c, hipMemcpyAsync(c->B[0] + c->meta.boff[i], B[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->factors_set = true;
+    c->pending_loss = false;
+    return 0;
+}
+
+extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH, float* const* B)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!c->factors_set) return fail(c, ALPINE_ERR_STATE, "factors were never set");
+    if ((H && ldH < c->N)) return fail(c, ALPINE_ERR_BAD_ARG, "ldH too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int K = c->K, KP = c->KP;
+    if (W) {
+        const int64_t n = (int64_t)c->G * K;
+        hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->W, KP, c->stage, (int64_t)K, (int64_t)c->G, K);
+        HIPCHK(c, hipMemcpyAsync(W, c->stage, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (H) {
+        dim3 grid((K + 31) / 32, (unsigned)((c->N + 31) / 32));
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->H, (int64_t)KP, c->stage, (int64_t)c->N, c->N, K);
+        HIPCHK(c, hipMemcpy2DAsync(H, sizeof(float) * ldH, c->stage, sizeof(float) * c->N, sizeof(float) * c->N, (size_t)K, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (B) for (int i = 0; i < c->n_cov; ++i) if (B[i])
+        HIPCHK(c, hipMemcpyAsync(B[i], c->B[c->bcur] + c->meta.boff[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- iteration
+static int prof_begin(alpine_ctx* c, int which)
+{
+    if (!c->prof) return 0;
+    auto& v = c->ev[which];
+    if (c->ev_used[which] == v.size()) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        v.emplace_back(a, b);
+    }
+    HIPCHK(c, hipEventRecord(v[c->ev_used[which]].first, c->stream));
+    return 0;
+}
+static int prof_end(alpine_ctx* c, int which)
+{
+    if (!c->prof) return 0;
+    HIPCHK(c, hipEventRecord(c->ev[which][c->ev_used[which]].second, c->stream));
+    c->ev_used[which]++;
+    return 0;
+}
+
+static int launch_reduce(alpine_ctx* c, const float* in, float* out, int64_t n, int nslab)
+{
+    const int64_t n4 = n / 4;
+    const int blocks = (int)std::min<int64_t>(c->n_cu * 8, (n4 + 255) / 256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(std::max(1, blocks)), dim3(256), 0, c->stream, in, out, n, nslab);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int blocks, float* out)
+{
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(gram_kernel<KT_>, dim3(blocks), dim3(256), 0, c->stream, A, c->gramPart, (int)R));
+    HIPCHK(c, hipGetLastError());
+    return launch_reduce(c, c->gramPart, out, (int64_t)c->KP * c->KP, blocks * 4);
+}
+
+static int ready(alpine_ctx* c)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!c->x_final) return fail(c, ALPINE_ERR_STATE, "X not finalised (alpine_upload_X_* then alpine_finalize_X)");
+    if (!c->factors_set) return fail(c, ALPINE_ERR_STATE, "factors not set (alpine_set_factors)");
+    for (int i = 0; i < c->n_cov; ++i) if (!c->y_set[i]) return fail(c, ALPINE_ERR_STATE, "Y[%d] not uploaded", i);
+    HIPCHK(c, hipSetDevice(c->device));
+    return 0;
+}
+
+extern "C" int alpine_iter_begin(alpine_ctx* c)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    const int KP = c->KP;
+    if (c->n_cov > 0) {
+        hipLaunchKernelGGL(hstats_kernel, dim3(c->statBlocks), dim3(HS_CELLS), 0, c->stream, c->H, c->Y, c->B[c->bcur], c->meta,
+                           c->statPart, c->N, c->Np, KP, (float)c->eps, c->nstat);
+        HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,
+                       c->statBlocks, c->nstat, c->xnorm2);
+    HIPCHK(c, hipGetLastError());
+    rc = launch_gram(c, c->H, c->Np, c->gramBlocksH, c->red + c->red_hht);
+    if (rc) return rc;
+    if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(stream_gemm_kernel<KT_>, dim3(c->gridA), dim3(SG_THREADS), 0, c->stream,
+                                           c->Xng, c->H, c->slabA, c->Gp, (int)c->Gp, (int)c->Np, c->rpsA, c->nftA));
+    HIPCHK(c, hipGetLastError());
+    if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
+    return launch_reduce(c, c->slabA, c->red, c->Gp * KP, c->splitA);
+}
+
+static int grow_losses(alpine_ctx* c)
+{
+    const int w = c->n_cov + 2;
+    double* bigger = nullptr;
+    HIPCHK(c, hipMalloc((void**)&bigger, sizeof(double) * c->loss_cap * 2 * w));
+    HIPCHK(c, hipMemcpyAsync(bigger, c->loss_dev, sizeof(double) * c->loss_rows * w, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(c->loss_dev));
+    c->bytes += sizeof(double) * c->loss_cap * w;
+    c->loss_dev = bigger;
+    c->loss_cap *= 2;
+    return 0;
+}
+
+extern "C" int alpine_iter_end(alpine_ctx* c, int update)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    const int KP = c->KP, K = c->K;
+    const float l2 = (float)((1.0 - c->l1r) * c->alpha), l1 = (float)(c->l1r * c->alpha);
+    const int wblocks = c->ndot / 4;
+    const size_t m_bytes = sizeof(float) * KP * KP;
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_kernel<KT_>, dim3(wblocks), dim3(256), m_bytes, c->stream, c->W, c->red,
+                                           c->red + c->red_hht, c->dotpart, c->G, K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0));
+    HIPCHK(c, hipGetLastError());
+    if (c->pending_loss && c->loss_enabled) {
+        if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, c->red + c->red_hht,
+                           c->red + c->red_stats, c->meta, c->nstat, KP, c->lam_dev, c->loss_dev + c->loss_rows * (c->n_cov + 2));
+        HIPCHK(c, hipGetLastError());
+        c->loss_rows++;
+    }
+    c->pending_loss = false;
+    if (!update) return 0;
+
+    if (c->n_cov > 0) {
+        hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
+                           c->red + c->red_hht, c->meta, KP, (float)c->eps);
+        HIPCHK(c, hipGetLastError());
+        c->bcur ^= 1;
+    }
+    rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW);
+    if (rc) return rc;
+    if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(stream_gemm_kernel<KT_>, dim3(c->gridB), dim3(SG_THREADS), 0, c->stream,
+                                           c->Xgn, c->W, c->slabB, c->Np, (int)c->Np, (int)c->Gp, c->rpsB, c->nftB));
+    HIPCHK(c, hipGetLastError());
+    if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    const int hblocks = (int)((c->N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
+    const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->slabB, c->splitB,
+                                           c->Np * (int64_t)KP, c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
+    HIPCHK(c, hipGetLastError());
+    c->pending_loss = true;
+    return 0;
+}
+
+extern "C" int alpine_reduce_block(alpine_ctx* c, void** dev_ptr, int64_t* n_floats)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (dev_ptr) *dev_ptr = c->red;
+    if (n_floats) *n_floats = c->red_floats;
+    return 0;
+}
+
+extern "C" int alpine_run(alpine_ctx* c, int n_iters, int with_loss)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (n_iters < 0) return fail(c, ALPINE_ERR_BAD_ARG, "n_iters must be >= 0");
+    c->loss_enabled = with_loss != 0;
+    for (int it = 0; it < n_iters; ++it) {
+        if ((rc = alpine_iter_begin(c))) return rc;
+        if ((rc = alpine_iter_end(c, 1))) return rc;
+    }
+    if (with_loss && c->pending_loss) {
+        if ((rc = alpine_iter_begin(c))) return rc;
+        if ((rc = alpine_iter_end(c, 0))) return rc;
+    }
+    c->loss_enabled = true;
+    return 0;
+}
+
+extern "C" int alpine_get_losses(alpine_ctx* c, double* rows, int64_t max_rows, int64_t* n_rows)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int64_t n = std::min(max_rows, c->loss_rows);
+    if (rows && n > 0) HIPCHK(c, hipMemcpy(rows, c->loss_dev, sizeof(double) * n * (c->n_cov + 2), hipMemcpyDeviceToHost));
+    if (n_rows) *n_rows = c->loss_rows;
+    return 0;
+}
+
+extern "C" int alpine_reset_losses(alpine_ctx* c)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    c->loss_rows = 0;
+    return 0;
+}
+
+extern "C" int alpine_scale(alpine_ctx* c)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    const int KP = c->KP, K = c->K;
+    const int rows_per_block = 256;
+    const int nblk = (c->G + rows_per_block - 1) / rows_per_block;
+    if ((int64_t)nblk * KP > c->f64part_n) return fail(c, ALPINE_ERR_UNSUPPORTED, "too many genes for the scaling scratch");
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(nblk), dim3(256), 0, c->stream, c->W, KP, c->G, rows_per_block, c->f64part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, c->stream, c->f64part, nblk, KP, c->scale);
+    const int64_t nw = (int64_t)c->G * K, nh = (int64_t)c->N * K;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, c->stream, c->W, KP, (int64_t)c->G, K, c->scale, 1);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, c->stream, c->H, KP, (int64_t)c->N, K, c->scale, 0);
+    if (c->n_cov > 0) hipLaunchKernelGGL(scale_b_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->meta, c->scale);
+    HIPCHK(c, hipGetLastError());
+    c->pending_loss = false;      // W^TW / reduce terms no longer describe these factors
+    return 0;
+}
+
+extern "C" int alpine_synchronize(alpine_ctx* c)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int alpine_eval_recon_direct(alpine_ctx* c, double* out)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (!out) return fail(c, ALPINE_ERR_BAD_ARG, "out is NULL");
+    const int gx = (c->G + 255) / 256;
+    int cells_per_block = 256;
+    while ((int64_t)gx * ((c->N + cells_per_block - 1) / cells_per_block) > c->f64part_n) cells_per_block *= 2;
+    const int gy = (c->N + cells_per_block - 1) / cells_per_block;
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(eval_recon_kernel<KT_>, dim3(gx, gy), dim3(256), 0, c->stream, c->Xng, c->Gp, c->W, c->H,
+                                           c->G, c->N, cells_per_block, c->f64part));
+    HIPCHK(c, hipGetLastError());
+    return sum_f64_partials(c, gx * gy, out);
+}
+
+extern "C" int alpine_set_profiling(alpine_ctx* c, int enabled)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    c->prof = enabled != 0;
+    for (int k = 0; k < ALPINE_KERNEL_COUNT; ++k) c->ev_used[k] = 0;
+    return 0;
+}
+
+extern "C" int alpine_get_kernel_time(alpine_ctx* c, int which, double* total_ms, int64_t* launches)
+{
+    if (!c || which < 0 || which >= ALPINE_KERNEL_COUNT) return fail(c, ALPINE_ERR_BAD_ARG, "bad kernel id");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double t = 0;
+    for (size_t i = 0; i < c->ev_used[which]; ++i) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[which][i].first, c->ev[which][i].second));
+        t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = (int64_t)c->ev_used[which];
+    return 0;
+}
+
+extern "C" int alpine_read_buffer(alpine_ctx* c, int which, int64_t offset, int64_t n, float* host)
+{
+    if (!c || !host || offset < 0 || n < 0) return fail(c, ALPINE_ERR_BAD_ARG, "bad arguments");
+    const float* base = nullptr; int64_t size = 0;
+    switch (which) {
+        case ALPINE_BUF_REDUCE_BLOCK: base = c->red; size = c->red_floats; break;
+        case ALPINE_BUF_WTW: base = c->WtW; size = (int64_t)c->KP * c->KP; break;
+        case ALPINE_BUF_W: base = c->W; size = c->Gp * c->KP; break;
+        case ALPINE_BUF_H: base = c->H; size = c->Np * c->KP; break;
+        case ALPINE_BUF_X_GENES_BY_CELLS: base = c->Xgn; size = c->Gp * c->Np; break;
+        case ALPINE_BUF_X_CELLS_BY_GENES: base = c->Xng; size = c->Np * c->Gp; break;
+        default: return fail(c, ALPINE_ERR_BAD_ARG, "unknown buffer %d", which);
+    }
+    if (offset + n > size) return fail(c, ALPINE_ERR_BAD_ARG, "range outside buffer (%lld floats)", (long long)size);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host, base + offset, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return 0;
+}

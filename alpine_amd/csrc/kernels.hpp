@@ -1,0 +1,764 @@
+// Device kernels of libalpine_hip.so (gfx950 / CDNA4 only).
+//
+// One MU iteration of ALPINE (alpine/main.py:589-663, loss :726-753) is evaluated as
+//
+//   phase 1 (old H, old B; everything here is a SUM OVER CELLS -> the multi-GPU reduce block)
+//     hstats_kernel      per-cell covariate terms: B-update numerators/denominators (:617-626),
+//                        prediction-loss sums (:727-731, :745-748)
+//     gram_kernel        HH^T  (the K x K factor of ((2W)H)H^T, :599, re-associated)
+//     stream_gemm_kernel XH^T  (:596) over the cells x genes copy of X      <- HOT, MFMA f32
+//   phase 2
+//     w_update_kernel    W <- W * 2XH^T / max(W(2HH^T + orth + l2 I) + l1, eps)  (:596-605, :474-484)
+//                        + float64 partials of <XH^T, W_old> for the trace-form loss
+//     loss_finalize      ||X||^2 - 2<XH^T,W> + <W^TW,HH^T>  (== :736), total (:750-752)
+//     b_update_kernel    (:615-628)
+//     gram_kernel        W^T W (the K x K factor of (2W^T)(WH), :654, re-associated)
+//     stream_gemm_kernel W^T X (:653) over the genes x cells copy of X      <- HOT, MFMA f32
+//     h_update_kernel    H <- H * (guided_num + 2W^TX) / max(guided_den + 2W^TW H, eps) (:631-656)
+//
+// Layouts (all float32, zero padded): X_gn [Gp][Np], X_ng [Np][Gp] (Gp, Np multiples of 128);
+// W [Gp][KP] gene-major, H [Np][KP] cell-major (KP = K rounded up to 32); Y [sum C_i][Np];
+// partial slabs [split][rows][KP].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace alpine {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MAX_COV = 16;       // covariates per model
+constexpr int MAX_COV_K = 64;     // guided components per covariate (and in total: they must sit in columns 0..63)
+
+struct CovMeta {
+    int n_cov;
+    int loss_type;                // 0 KL, 1 Frobenius
+    int off[MAX_COV];             // first column of the covariate's block in W / H
+    int k[MAX_COV];               // k_i
+    int lev[MAX_COV];             // C_i
+    int boff[MAX_COV];            // offset of B_i (C_i x k_i row-major) in the packed B buffer
+    int yoff[MAX_COV];            // first row of Y_i in the packed Y buffer
+    int soff[MAX_COV];            // offset of this covariate's statistics in the stats vector
+    float lam[MAX_COV];           // float32(lambda_i)
+    float lam2[MAX_COV];          // float32(2*lambda_i)
+};
+// statistics of covariate i: [bnum: C_i*k_i][bden: k_i][loss_hi][loss_lo]
+
+// ----------------------------------------------------------------------------------------------
+// stream_gemm: out[f][k] = sum_r S[r][f] * P[r][k]      S: R x ldS streamed once, P: R x KP panel
+//
+//   sweep XH^T : S = X_ng (cells x genes), P = H (cells x KP)  -> out[gene][k]
+//   sweep W^TX : S = X_gn (genes x cells), P = W (genes x KP)  -> out[cell][k]
+//
+// The contraction index r is the ROW index of both operands, so S is read with 16 B/lane loads
+// that are contiguous along f (1 KiB per wave-instruction = 2 rows x 512 B) straight into the MFMA
+// B operand -- no LDS round trip for the 16 GB stream -- and the small panel is staged through LDS
+// (double buffered, 16 rows per stage) and shared by the 4 waves of the workgroup.
+// v_mfma_f32_32x32x2_f32: A[i=l&31][kk=l>>5] = P[r+kk][32m+i], B[kk=l>>5][j=l&31] = S[r+kk][f(j)],
+// where the four B tiles of a wave interleave along f (tile t column j is f0 + 4j + t), so that one
+// float4 load feeds four MFMAs.  Work item = (512-wide f tile, split of the r range); partial results
+// go to slab[split][f][KP] and are summed in a fixed order downstream (deterministic, no atomics).
+constexpr int SG_THREADS = 256;
+constexpr int SG_WAVES = 4;
+constexpr int SG_WAVE_F = 128;
+constexpr int SG_BLOCK_F = SG_WAVES * SG_WAVE_F;
+constexpr int SG_CH = 16;            // rows per pipeline stage (8 MFMA k-steps)
+constexpr int SG_NP = SG_CH / 2;
+
+template <int KT>
+__device__ __forceinline__ void sg_compute(f32x16 (&acc)[KT][4], const f32x4 (&x)[SG_NP],
+                                           const float* __restrict__ lbuf, int c, int h)
+{
+    constexpr int KP = 32 * KT;
+#pragma unroll
+    for (int p = 0; p < SG_NP; ++p) {
+        float a[KT];
+#pragma unroll
+        for (int m = 0; m < KT; ++m) a[m] = lbuf[(2 * p + h) * KP + 32 * m + c];
+#pragma unroll
+        for (int m = 0; m < KT; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], x[p][j], acc[m][j], 0, 0, 0);
+        }
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(SG_THREADS, (KT <= 2 ? 2 : 1))
+void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P, float* __restrict__ slab,
+                        int64_t ldS, int F, int R, int rows_per_split, int n_ftiles)
+{
+    constexpr int KP = 32 * KT;
+    constexpr int PV = (4 * KP + SG_THREADS - 1) / SG_THREADS;   // float4 per thread per panel stage
+    __shared__ __attribute__((aligned(16))) float lds[2][SG_CH * KP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar branches
+    const int c = lane & 31, h = lane >> 5;
+    const int ft = blockIdx.x % n_ftiles;
+    const int sp = blockIdx.x / n_ftiles;
+    const int f0 = (ft * SG_WAVES + wave) * SG_WAVE_F;
+    const bool active = f0 < F;
+    const int r_begin = sp * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+    const int nch = (r_end - r_begin) / SG_CH;
+
+    f32x16 acc[KT][4];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+    const float* sptr = S + (int64_t)(r_begin + h) * ldS + (active ? f0 : 0) + 4 * c;
+    const float* pptr = P + (int64_t)r_begin * KP;
+    const int64_t s_stage = (int64_t)SG_CH * ldS;
+
+    f32x4 xa[SG_NP], xb[SG_NP], preg[PV];
+
+    auto load_x = [&](f32x4 (&x)[SG_NP], int ci) {
+        const float* q = sptr + ci * s_stage;
+#pragma unroll
+        for (int p = 0; p < SG_NP; ++p)
+            x[p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + (int64_t)(2 * p) * ldS));
+    };
+    auto load_p = [&](int ci) {
+        const float* q = pptr + (int64_t)ci * (SG_CH * KP);
+#pragma unroll
+        for (int v = 0; v < PV; ++v) {
+            const int idx = tid + SG_THREADS * v;
+            if (idx < 4 * KP) preg[v] = *reinterpret_cast<const f32x4*>(q + 4 * idx);
+        }
+    };
+    auto store_p = [&](int b) {
+#pragma unroll
+        for (int v = 0; v < PV; ++v) {
+            const int idx = tid + SG_THREADS * v;
+            if (idx < 4 * KP) *reinterpret_cast<f32x4*>(&lds[b][4 * idx]) = preg[v];
+        }
+    };
+
+    if (nch > 0) {
+        load_p(0);
+        if (active) load_x(xa, 0);
+        store_p(0);
+        if (nch > 1) load_p(1);
+        __syncthreads();
+
+        // stage ci: panel ci is in lds[ci&1], its X rows are in flight/landed in xc.
+        auto stage = [&](f32x4 (&xc)[SG_NP], f32x4 (&xn)[SG_NP], int ci) {
+            const int b = ci & 1;
+            if (ci + 1 < nch) store_p(b ^ 1);          // lds[b^1] was last read in stage ci-1 (barrier since)
+            if (ci + 2 < nch) load_p(ci + 2);
+            if (active) {
+                if (ci + 1 < nch) load_x(xn, ci + 1);
+                sg_compute<KT>(acc, xc, lds[b], c, h);
+            }
+            __syncthreads();
+        };
+        for (int ci = 0; ci < nch; ci += 2) {
+            stage(xa, xb, ci);
+            if (ci + 1 < nch) stage(xb, xa, ci + 1);
+        }
+    }
+
+    if (active) {
+        float* out = slab + ((int64_t)sp * F + f0 + 4 * c) * KP + 4 * h;
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = {acc[m][j][4 * q + 0], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
+                    // D row (k within tile m) = 8q + 4h + e, D column = lane&31 -> f = f0 + 4c + j
+                    *reinterpret_cast<f32x4*>(out + (int64_t)j * KP + 32 * m + 8 * q) = v;
+                }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// gram: part[w][k][k'] = sum_{r in rows of wave w} A[r][k] * A[r][k']     (A: R x KP, row-major)
+// Used for HH^T (A = H) and W^TW (A = W).  Each wave owns a contiguous row range; A and B MFMA
+// operands are the same registers.
+constexpr int GR_ROWS_PER_WAVE = 256;
+
+template <int KT>
+__global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
+void gram_kernel(const float* __restrict__ A, float* __restrict__ part, int R)
+{
+    constexpr int KP = 32 * KT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave;
+    const int r0 = gw * GR_ROWS_PER_WAVE;
+    const int r1 = min(R, r0 + GR_ROWS_PER_WAVE);      // R is a multiple of 16
+
+    f32x16 acc[KT][KT];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    for (int r = r0; r < r1; r += 8) {
+        float v[4][KT];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int m = 0; m < KT; ++m) v[p][m] = A[(int64_t)(r + 2 * p + h) * KP + 32 * m + c];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int b = 0; b < KT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][a], v[p][b], acc[a][b], 0, 0, 0);
+    }
+    float* out = part + (int64_t)gw * KP * KP;
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[row * KP + 32 * b + c] = acc[a][b][e];
+            }
+}
+
+// out[i] = sum_s in[s][i] (float64 accumulation, fixed order), i < n (n multiple of 4)
+__global__ __launch_bounds__(256)
+void reduce_slabs_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int nslab)
+{
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int s = 0; s < nslab; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in + (int64_t)s * n + 4 * i);
+            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+        }
+        f32x4 o = {(float)a0, (float)a1, (float)a2, (float)a3};
+        *reinterpret_cast<f32x4*>(out + 4 * i) = o;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int src)   // src must be a compile-time constant
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// ----------------------------------------------------------------------------------------------
+// hstats: per block of 128 cells, for every covariate i (old H_i, old B_i):
+//   KL  (:617-623, :727-731): bnum[c][k] = sum_n (lam*(Y/max(BH,eps)))[c][n] * H[k][n],  bden[k] = sum_n lam*H[k][n]
+//                             loss = sum (y*log(max(y/yhat,eps)) - y + yhat)
+//   Fro (:625-626, :745-748): bnum[c][k] = sum_n Y[c][n]*H[k][n]  (the 2* and the B HH^T side come later)
+//                             loss = sum (y - BH)^2
+constexpr int HS_CELLS = 128;
+constexpr int HS_CT = 16;
+
+__global__ __launch_bounds__(HS_CELLS)
+void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, const float* __restrict__ B,
+                   CovMeta meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat)
+{
+    __shared__ float hbuf[MAX_COV_K][HS_CELLS];
+    __shared__ float zbuf[HS_CT][HS_CELLS];
+    __shared__ float Bl[HS_CT][MAX_COV_K];
+    __shared__ double lred[HS_CELLS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t n = (int64_t)blockIdx.x * HS_CELLS + t;
+    const bool valid = n < N;
+    float* out = part + (int64_t)blockIdx.x * nstat;
+
+    for (int i = 0; i < meta.n_cov; ++i) {
+        const int ki = meta.k[i], Ci = meta.lev[i], off = meta.off[i];
+        const float lam = meta.lam[i];
+        float* so = out + meta.soff[i];
+        __syncthreads();
+        for (int k = 0; k < ki; ++k) hbuf[k][t] = valid ? H[n * KP + off + k] : 0.f;
+        double lacc = 0.0;
+        for (int c0 = 0; c0 < Ci; c0 += HS_CT) {
+            const int ct = min(HS_CT, Ci - c0);
+            __syncthreads();
+            for (int idx = t; idx < ct * ki; idx += HS_CELLS)
+                Bl[idx / ki][idx % ki] = B[meta.boff[i] + (c0 + idx / ki) * ki + idx % ki];
+            __syncthreads();
+            for (int c = 0; c < ct; ++c) {
+                float bh = 0.f;
+                for (int k = 0; k < ki; ++k) bh = fmaf(Bl[c][k], hbuf[k][t], bh);
+                const float y = valid ? Y[(int64_t)(meta.yoff[i] + c0 + c) * Np + n] : 0.f;
+                float z;
+                if (meta.loss_type == 0) {
+                    const float yh = fmaxf(bh, eps);
+                    z = lam * (y / yh);
+                    if (valid) lacc += (double)(y * logf(fmaxf(y / yh, eps)) - y + yh);
+                } else {
+                    z = y;
+                    const float d = y - bh;
+                    if (valid) lacc += (double)(d * d);
+                }
+                zbuf[c][t] = valid ? z : 0.f;
+            }
+            __syncthreads();
+            for (int p = wave; p < ct * ki; p += HS_CELLS / 64) {
+                const int c = p / ki, k = p % ki;
+                float v = zbuf[c][lane] * hbuf[k][lane];
+                v = fmaf(zbuf[c][lane + 64], hbuf[k][lane + 64], v);
+                v = wave_sum_f32(v);
+                if (lane == 0) so[(c0 + c) * ki + k] = v;
+            }
+        }
+        for (int k = wave; k < ki; k += HS_CELLS / 64) {
+            float v = lam * hbuf[k][lane] + lam * hbuf[k][lane + 64];
+            v = wave_sum_f32(v);
+            if (lane == 0) so[Ci * ki + k] = v;
+        }
+        lred[t] = lacc;
+        __syncthreads();
+        for (int s = HS_CELLS / 2; s > 0; s >>= 1) {
+            if (t < s) lred[t] += lred[t + s];
+            __syncthreads();
+        }
+        if (t == 0) {
+            const float hi = (float)lred[0];
+            so[Ci * ki + ki] = hi;
+            so[Ci * ki + ki + 1] = (float)(lred[0] - (double)hi);
+        }
+    }
+}
+
+// stats[j] = sum over blocks of part[blk][j] in float64; kind[j]: 0 plain, 1 = hi word of a (hi,lo) pair
+// whose lo word is j+1 (summed together, re-split), 2 = lo word (written by its hi's block).
+// Block nstat writes (hi,lo) of ||X_local||^2 at stats[nstat], stats[nstat+1].
+__global__ __launch_bounds__(256)
+void reduce_stats_kernel(const float* __restrict__ part, const int* __restrict__ kind, float* __restrict__ stats,
+                         int nblk, int nstat, double xnorm2)
+{
+    __shared__ double red[256];
+    const int j = blockIdx.x, t = threadIdx.x;
+    if (j == nstat) {
+        if (t == 0) {
+            const float hi = (float)xnorm2;
+            stats[nstat] = hi;
+            stats[nstat + 1] = (float)(xnorm2 - (double)hi);
+        }
+        return;
+    }
+    const int kd = kind[j];
+    if (kd == 2) return;
+    double a = 0.0;
+    for (int b = t; b < nblk; b += 256) {
+        a += (double)part[(int64_t)b * nstat + j];
+        if (kd == 1) a += (double)part[(int64_t)b * nstat + j + 1];
+    }
+    red[t] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float hi = (float)red[0];
+        stats[j] = hi;
+        if (kd == 1) stats[j + 1] = (float)(red[0] - (double)hi);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// w_update: rows of W, one wave per 8 gene rows, lane = column k (two columns per lane when KP > 64).
+//   den[g][k] = sum_k' W[g][k'] * M[k'][k] + l1 ,  M = 2 HH^T + orth*(1 - I) + l2*I   (K x K, in LDS)
+//   W[g][k]  *= (2 XH^T[g][k]) / max(den, eps)                                   main.py:596-605
+// Also dotpart[wave] = sum over its rows of XH^T[g][k] * W_old[g][k] in float64 (trace-form loss).
+constexpr int UPD_ROWS = 8;
+
+template <int KT>
+__global__ __launch_bounds__(256)
+void w_update_kernel(float* __restrict__ W, const float* __restrict__ XHt, const float* __restrict__ HHt,
+                     double* __restrict__ dotpart, int G, int K, float orth, float l2, float l1, float eps,
+                     int do_update)
+{
+    constexpr int KP = 32 * KT;
+    constexpr int NH = (KP + 63) / 64;
+    extern __shared__ float M[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (do_update) {
+        for (int idx = tid; idx < KP * KP; idx += 256) {
+            const int kp = idx / KP, k = idx % KP;
+            float v = 0.f;
+            if (kp < K && k < K) v = 2.f * HHt[idx] + (kp == k ? l2 : orth);
+            M[idx] = v;
+        }
+        __syncthreads();
+    }
+    const int gw = blockIdx.x * 4 + wave;
+    const int g0 = gw * UPD_ROWS;
+    float w[UPD_ROWS][NH], x[UPD_ROWS][NH];
+#pragma unroll
+    for (int i = 0; i < UPD_ROWS; ++i)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const int k = lane + 64 * hh;
+            const bool ok = (g0 + i < G) && (k < KP);
+            w[i][hh] = ok ? W[(int64_t)(g0 + i) * KP + k] : 0.f;
+            x[i][hh] = ok ? XHt[(int64_t)(g0 + i) * KP + k] : 0.f;
+        }
+    double dacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < UPD_ROWS; ++i)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) dacc += (double)x[i][hh] * (double)w[i][hh];
+    dacc = wave_sum_f64(dacc);
+    if (lane == 0) dotpart[gw] = dacc;
+    if (!do_update) return;
+
+    float den[UPD_ROWS][NH];
+#pragma unroll
+    for (int i = 0; i < UPD_ROWS; ++i)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) den[i][hh] = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+        float mk[NH];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) mk[hh] = (lane + 64 * hh < KP) ? M[kp * KP + lane + 64 * hh] : 0.f;
+#pragma unroll
+        for (int i = 0; i < UPD_ROWS; ++i) {
+            const float wv = lane_bcast(w[i][kp >> 6], kp & 63);
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) den[i][hh] = fmaf(wv, mk[hh], den[i][hh]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < UPD_ROWS; ++i)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const int k = lane + 64 * hh;
+            if (g0 + i < G && k < K) {
+                const float d = fmaxf(den[i][hh] + l1, eps);
+                W[(int64_t)(g0 + i) * KP + k] = w[i][hh] * ((2.f * x[i][hh]) / d);
+            }
+        }
+}
+
+// ----------------------------------------------------------------------------------------------
+// h_update: rows of H (cells), one wave per 8 cells, lane = component k.
+//   num = guided_num + 2 * sum_s slabB[s][n][k]
+//   den = guided_den + sum_k' (2 W^TW)[k'][k] * H[n][k']
+//   H[n][k] *= num / max(den, eps)                                              main.py:631-656
+// guided terms for the columns of covariate i (lanes off_i .. off_i+k_i-1, all within lanes 0..63):
+//   KL : num = sum_c (lam B[c][k]) * (Y[c][n] / max((B H_i)[c][n], eps)),  den = sum_c lam B[c][k]   (:639-644)
+//   Fro: num = sum_c (2 lam B[c][k]) * Y[c][n],  den = sum_c (2 lam B[c][k]) * (B H_i)[c][n]          (:646-647)
+template <int KT>
+__global__ __launch_bounds__(256)
+void h_update_kernel(float* __restrict__ H, const float* __restrict__ slab, int nslab, int64_t slab_stride,
+                     const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
+                     CovMeta meta, int N, int64_t Np, int K, float eps, int nB)
+{
+    constexpr int KP = 32 * KT;
+    constexpr int NH = (KP + 63) / 64;
+    extern __shared__ float smem[];
+    float* M = smem;               // KP*KP : 2 W^T W
+    float* Bl = smem + KP * KP;    // packed B (nB floats)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < KP * KP; idx += 256) M[idx] = 2.f * WtW[idx];
+    for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];
+    __syncthreads();
+
+    // which covariate block does column `lane` belong to?
+    int ci = -1, coff = 0, ck = 0, cC = 0, cb = 0, cy = 0;
+    float clam = 0.f;
+    int kmax = 0, Cmax = 0;
+    for (int i = 0; i < meta.n_cov; ++i) {
+        kmax = max(kmax, meta.k[i]);
+        Cmax = max(Cmax, meta.lev[i]);
+        if (lane >= meta.off[i] && lane < meta.off[i] + meta.k[i]) {
+            ci = i; coff = meta.off[i]; ck = meta.k[i]; cC = meta.lev[i]; cb = meta.boff[i]; cy = meta.yoff[i];
+            clam = (meta.loss_type == 0) ? meta.lam[i] : meta.lam2[i];
+        }
+    }
+
+    const int gw = blockIdx.x * 4 + wave;
+    const int64_t n0 = (int64_t)gw * UPD_ROWS;
+    float hv[UPD_ROWS][NH], xv[UPD_ROWS][NH], den[UPD_ROWS][NH];
+#pragma unroll
+    for (int i = 0; i < UPD_ROWS; ++i)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const int k = lane + 64 * hh;
+            const bool ok = (n0 + i < N) && (k < KP);
+            hv[i][hh] = ok ? H[(n0 + i) * KP + k] : 0.f;
+            double a = 0.0;
+            if (ok) for (int s = 0; s < nslab; ++s) a += (double)slab[(int64_t)s * slab_stride + (n0 + i) * KP + k];
+            xv[i][hh] = (float)a;
+            den[i][hh] = 0.f;
+        }
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+        float mk[NH];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) mk[hh] = (lane + 64 * hh < KP) ? M[kp * KP + lane + 64 * hh] : 0.f;
+#pragma unroll
+        for (int i = 0; i < UPD_ROWS; ++i) {
+            const float b = lane_bcast(hv[i][kp >> 6], kp & 63);
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) den[i][hh] = fmaf(b, mk[hh], den[i][hh]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < UPD_ROWS; ++i) {
+        float gnum = 0.f, gden = 0.f;
+        for (int c = 0; c < Cmax; ++c) {
+            float bh = 0.f;
+            for (int kk = 0; kk < kmax; ++kk) {
+                const bool on = (ci >= 0) && (kk < ck) && (c < cC);
+                const float hs = __shfl(hv[i][0], on ? coff + kk : lane, 64);
+                const float bc = on ? Bl[cb + c * ck + kk] : 0.f;
+                bh = fmaf(bc, hs, bh);
+            }
+            if (ci >= 0 && c < cC && n0 + i < N) {
+                const float y = Y[(int64_t)(cy + c) * Np + n0 + i];
+                const float lb = clam * Bl[cb + c * ck + (lane - coff)];
+                if (meta.loss_type == 0) {
+                    gnum = fmaf(lb, y / fmaxf(bh, eps), gnum);
+                    gden += lb;
+                } else {
+                    gnum = fmaf(lb, y, gnum);
+                    gden = fmaf(lb, bh, gden);
+                }
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const int k = lane + 64 * hh;
+            if (n0 + i < N && k < K) {
+                const float num = (hh == 0 ? gnum : 0.f) + 2.f * xv[i][hh];
+                const float d = fmaxf((hh == 0 ? gden : 0.f) + den[i][hh], eps);
+                H[(n0 + i) * KP + k] = hv[i][hh] * (num / d);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// b_update (one block): B_i <- B_i * num / max(den, eps), main.py:615-628, from the reduced statistics.
+__global__ __launch_bounds__(256)
+void b_update_kernel(const float* __restrict__ Bold, float* __restrict__ Bnew, const float* __restrict__ stats,
+                     const float* __restrict__ HHt, CovMeta meta, int KP, float eps)
+{
+    for (int i = 0; i < meta.n_cov; ++i) {
+        const int ki = meta.k[i], Ci = meta.lev[i], off = meta.off[i];
+        const float* st = stats + meta.soff[i];
+        for (int idx = threadIdx.x; idx < Ci * ki; idx += blockDim.x) {
+            const int c = idx / ki, k = idx % ki;
+            const float b = Bold[meta.boff[i] + idx];
+            float num, den;
+            if (meta.loss_type == 0) {
+                num = st[idx];
+                den = st[Ci * ki + k];
+            } else {
+                num = 2.f * st[idx];
+                den = 0.f;
+                for (int kk = 0; kk < ki; ++kk)
+                    den = fmaf(2.f * Bold[meta.boff[i] + c * ki + kk], HHt[(off + kk) * KP + off + k], den);
+            }
+            Bnew[meta.boff[i] + idx] = b * (num / fmaxf(den, eps));
+        }
+    }
+}
+
+// loss_finalize (one block): row = [total, recon, pred_1..pred_C] in float64, main.py:726-753 with
+// recon = ||X||^2 - 2 <XH^T, W> + <W^TW, HH^T>  (all three terms belong to the same (W, H)).
+__global__ __launch_bounds__(256)
+void loss_finalize_kernel(const double* __restrict__ dotpart, int ndot, const float* __restrict__ WtW,
+                          const float* __restrict__ HHt, const float* __restrict__ stats, CovMeta meta,
+                          int nstat, int KP, const double* __restrict__ lam64, double* __restrict__ row)
+{
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    double a = 0.0;
+    for (int i = t; i < ndot; i += 256) a -= 2.0 * dotpart[i];
+    for (int i = t; i < KP * KP; i += 256) a += (double)WtW[i] * (double)HHt[i];
+    red[t] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double xn = (double)stats[nstat] + (double)stats[nstat + 1];
+        const double recon = xn + red[0];
+        double total = recon;
+        for (int i = 0; i < meta.n_cov; ++i) {
+            const int o = meta.soff[i] + meta.lev[i] * meta.k[i] + meta.k[i];
+            const double pl = (double)stats[o] + (double)stats[o + 1];
+            row[2 + i] = pl;
+            total += lam64[i] * pl;
+        }
+        row[0] = total;
+        row[1] = recon;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// ingest helpers
+__global__ __launch_bounds__(256)
+void transpose_kernel(const float* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int64_t ld_dst,
+                      int rows, int cols)                       // dst[c][r] = src[r][c]
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? src[(int64_t)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) dst[(int64_t)c * ld_dst + r] = tile[tx][j];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void sqnorm_kernel(const float* __restrict__ x, int64_t n4, double* __restrict__ part)
+{
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        a += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// pack / unpack between the caller's (row-major, unpadded) factors and the padded device layouts
+__global__ void pad_rows_kernel(const float* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int KP,
+                                int64_t rows, int K)            // dst[r][k<K] = src[r][k]
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * K) return;
+    const int64_t r = i / K;
+    const int k = (int)(i % K);
+    dst[r * KP + k] = src[r * ld_src + k];
+}
+__global__ void unpad_rows_kernel(const float* __restrict__ src, int KP, float* __restrict__ dst, int64_t ld_dst,
+                                  int64_t rows, int K)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * K) return;
+    const int64_t r = i / K;
+    const int k = (int)(i % K);
+    dst[r * ld_dst + k] = src[r * KP + k];
+}
+
+// ----------------------------------------------------------------------------------------------
+// scaling, main.py:772-781
+__global__ __launch_bounds__(256)
+void colsum_part_kernel(const float* __restrict__ W, int KP, int G, int rows_per_block, double* __restrict__ part)
+{
+    const int k = threadIdx.x;
+    if (k >= KP) return;
+    const int g0 = blockIdx.x * rows_per_block, g1 = min(G, g0 + rows_per_block);
+    double a = 0.0;
+    for (int g = g0; g < g1; ++g) a += (double)W[(int64_t)g * KP + k];
+    part[(int64_t)blockIdx.x * KP + k] = a;
+}
+__global__ __launch_bounds__(256)
+void colsum_final_kernel(const double* __restrict__ part, int nblk, int KP, float* __restrict__ scale)
+{
+    const int k = threadIdx.x;
+    if (k >= KP) return;
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += part[(int64_t)b * KP + k];
+    scale[k] = (float)a;
+}
+__global__ void scale_rows_kernel(float* __restrict__ A, int KP, int64_t rows, int K, const float* __restrict__ scale,
+                                  int divide)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * K) return;
+    const int64_t r = i / K;
+    const int k = (int)(i % K);
+    const float s = scale[k];
+    float v = A[r * KP + k];
+    A[r * KP + k] = divide ? v / s : v * s;
+}
+__global__ void scale_b_kernel(float* __restrict__ B, CovMeta meta, const float* __restrict__ scale)
+{
+    for (int i = 0; i < meta.n_cov; ++i)
+        for (int idx = threadIdx.x; idx < meta.lev[i] * meta.k[i]; idx += blockDim.x)
+            B[meta.boff[i] + idx] /= scale[meta.off[i] + idx % meta.k[i]];
+}
+
+// ----------------------------------------------------------------------------------------------
+// direct-form ||X - W H||^2 in float64 (validation only).  Block = 256 genes x a range of cells;
+// thread = gene, its W row lives in registers, H rows are broadcast from LDS.
+constexpr int EV_CELLS = 32;
+
+template <int KT>
+__global__ __launch_bounds__(256)
+void eval_recon_kernel(const float* __restrict__ Xng, int64_t ldG, const float* __restrict__ W,
+                       const float* __restrict__ H, int G, int N, int cells_per_block, double* __restrict__ part)
+{
+    constexpr int KP = 32 * KT;
+    __shared__ float hl[EV_CELLS][KP];
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    const int g = blockIdx.x * 256 + t;
+    float w[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) w[k] = (g < G) ? W[(int64_t)g * KP + k] : 0.f;
+    const int n0 = blockIdx.y * cells_per_block, n1 = min(N, n0 + cells_per_block);
+    double acc = 0.0;
+    for (int nb = n0; nb < n1; nb += EV_CELLS) {
+        __syncthreads();
+        for (int idx = t; idx < EV_CELLS * KP; idx += 256) {
+            const int r = idx / KP, k = idx % KP;
+            hl[r][k] = (nb + r < n1) ? H[(int64_t)(nb + r) * KP + k] : 0.f;
+        }
+        __syncthreads();
+        const int lim = min(EV_CELLS, n1 - nb);
+        for (int r = 0; r < lim; ++r) {
+            float p = 0.f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) p = fmaf(w[k], hl[r][k], p);
+            if (g < G) {
+                const double d = (double)Xng[(int64_t)(nb + r) * ldG + g] - (double)p;
+                acc += d * d;
+            }
+        }
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+}  // namespace alpine

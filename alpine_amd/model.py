@@ -1,0 +1,304 @@
+"""``ALPINE`` -- host-side mirror of the reference's model class for the path this package
+accelerates: ``ALPINE(**params).fit(adata, covariate_keys=...)`` / ``store_embeddings`` with the
+full-batch multiplicative-update loop running on one MI355X (or cell-sharded over several, one
+process per GPU) through libalpine_hip.so.
+
+Mirrors alpine/main.py:46-147, :303-434 (constructor, validators with the same messages and
+quirks, fit orchestration, result dict, AnnData write-back).  The numerical loop itself
+(main.py:486-676) is NOT here -- it is the HIP library.  There is no CPU execution path in this
+class: ``device="cpu"`` raises.
+"""
+from __future__ import annotations
+
+import math
+from copy import copy
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import _native
+from .anndata_compat import is_anndata
+from .encoder import FeatureEncoders
+from .sharded import ShardedLoop, TorchDistComm, shard_bounds
+
+Float32Array = np.ndarray
+
+
+def draw_initial_factors(random_state: int, eps: float, n_features: int, n_samples: int,
+                         n_all_components: List[int], cov_levels: List[int]):
+    """The reference's initial draws (main.py:440, :454-470) on the torch CPU generator: reseed,
+    then every W_j (G x k_j), every H_j (k_j x N), every B_i (C_i x k_i), each ``U[0,1)`` clamped
+    from below at eps.  Returns W (G x K), H (K x N), [B_i] as float32 numpy arrays."""
+    torch.manual_seed(random_state)
+    Ws = [torch.rand((n_features, k), dtype=torch.float32).clamp(min=eps) for k in n_all_components]
+    Hs = [torch.rand((k, n_samples), dtype=torch.float32).clamp(min=eps) for k in n_all_components]
+    Bs = [torch.rand((c, k), dtype=torch.float32).clamp(min=eps) for c, k in zip(cov_levels, n_all_components)]
+    return torch.cat(Ws, dim=1).numpy(), torch.cat(Hs, dim=0).numpy(), [b.numpy() for b in Bs]
+
+
+def _parse_device(device: str) -> int:
+    d = torch.device(device)
+    if d.type == "cpu":
+        raise ValueError(
+            "alpine_amd runs the fit loop on an MI355X through libalpine_hip.so and has no CPU path; "
+            "use device='cuda' (or 'cuda:<i>' / 'hip').")
+    if d.type not in ("cuda", "hip"):
+        raise ValueError(f"unsupported device {device!r}")
+    return d.index if d.index is not None else -1
+
+
+class ALPINE:
+    def __init__(
+        self,
+        n_components: int,
+        n_covariate_components: List[int],
+        lam: List[float],
+        orth_W: float = 0.0,
+        alpha_W: float = 0.0,
+        l1_ratio_W: float = 0.0,
+        use_als: bool = False,
+        scale_needed: bool = True,
+        loss_type: str = "kl-divergence",
+        device: str = "cuda",
+        eps: float = 1e-6,
+        random_state: int = 42,
+        shard_cells: bool = False,
+    ):
+        self.n_components = n_components
+        self.n_covariate_components = n_covariate_components
+        self.lam = lam
+        self.orth_W = orth_W
+        self.alpha_W = alpha_W
+        self.l1_ratio_W = l1_ratio_W
+        self.use_als = use_als
+        self.scale_needed = scale_needed
+        ds = str(device)
+        if ds == "hip" or ds.startswith("hip:"):
+            ds = "cuda" + ds[3:]
+        self.device = torch.device(ds)
+        self.loss_type = loss_type
+        self.eps = eps
+        self.random_state = random_state
+        # extension (not in the reference): shard the cell axis over the ranks of the default
+        # torch.distributed process group, one process per GPU.  Default: single device.
+        self.shard_cells = shard_cells
+
+        self._validate_init_args()
+
+        self.n_all_components = self.n_covariate_components + [self.n_components]     # main.py:79
+        self.total_components = sum(self.n_all_components)                            # main.py:80
+
+    # ------------------------------------------------------------------ fit (main.py:82-147)
+    def fit(
+        self,
+        adata,
+        covariate_keys: List[str],
+        batch_size: Optional[int] = None,
+        max_iter: Optional[int] = None,
+        sampling_method: str = "random",
+        verbose: bool = False,
+    ) -> "ALPINE":
+        self._validate_fit_args(adata, covariate_keys, batch_size, max_iter, sampling_method, verbose)
+        self.feature_names = adata.var_names.tolist()
+        self.n_features = adata.shape[1]
+        self.covariate_keys = covariate_keys
+        self.sampling_method = sampling_method
+        self.verbose = verbose
+
+        n_sample = adata.shape[0]
+        self.fe = FeatureEncoders(covariate_keys)
+        Y = self.fe.fit_transform(adata.obs)                       # list of N x C_i float32 (main.py:108-109)
+        self.batch_size = batch_size if batch_size is not None else n_sample
+        self._check_supported(n_sample)
+
+        if max_iter is None:
+            # main.py:116-129: 200-iteration warm-up, Kneedle elbow on log10(recon loss)
+            warm = self._run_native(adata.X, Y, 200, scale=False)
+            self.max_iter = self._compute_best_iter(warm["loss_history"]["reconstruction loss"].values)
+            del warm
+        else:
+            self.max_iter = max_iter
+
+        res = self._run_native(adata.X, Y, self.max_iter, scale=self.scale_needed)
+        self.loss_history = res["loss_history"]
+        offs = np.cumsum([0] + self.n_all_components)
+        X32 = adata.X if adata.X.dtype == np.float32 else adata.X.astype(np.float32)
+        self.matrices: Dict[str, Union[Float32Array, List[Float32Array]]] = {
+            "X": X32.T,                                                     # G x N view, not a device read-back (main.py:38)
+            "Ys": [np.ascontiguousarray(y.T) for y in Y],                   # C_i x N
+            "Ws": [np.ascontiguousarray(res["W"][:, offs[j]:offs[j + 1]]) for j in range(len(self.n_all_components))],
+            "Hs": [np.ascontiguousarray(res["H"][offs[j]:offs[j + 1]]) for j in range(len(self.n_all_components))],
+            "Bs": res["Bs"],
+        }
+        self.fit_info = res["info"]
+        self.store_embeddings(adata)
+        return self
+
+    def _check_supported(self, n_sample: int) -> None:
+        if self.use_als:
+            raise NotImplementedError("use_als=True (block-coordinate branch, main.py:523-588) is not part of the accelerated path yet")
+        if self.batch_size < n_sample:
+            raise NotImplementedError("mini-batch fitting (batch_size < n_cells, main.py:509-521) is not part of the accelerated path yet")
+        if self.sampling_method != "random":
+            if self.sampling_method == "weighted":
+                raise NotImplementedError("sampling_method='weighted' is not part of the accelerated path yet")
+            raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
+
+    def _run_native(self, X_cells_genes: np.ndarray, Y: List[np.ndarray], n_iter: int, scale: bool) -> dict:
+        """Upload, initialise exactly like main.py:436-472, run the MU loop on the device(s), read back."""
+        N_total, G = X_cells_genes.shape
+        dev_index = _parse_device(str(self.device))
+        import torch.distributed as dist
+        sharded = bool(self.shard_cells) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: alpine_amd needs an MI355X (there is no CPU fallback)")
+        if dev_index < 0:
+            dev_index = torch.cuda.current_device()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if sharded else (0, 1)
+        c0, c1 = shard_bounds(N_total, world, rank)
+        n_loc = c1 - c0
+        cov_levels = [y.shape[1] for y in Y]
+        W0, H0, B0 = draw_initial_factors(self.random_state, self.eps, G, N_total, self.n_all_components, cov_levels)
+
+        kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
+                  cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
+                  orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
+                  loss_type=self.loss_type, device_id=dev_index)
+        block = None
+        if sharded:
+            with torch.cuda.device(dev_index):
+                nfl = _native.reduce_block_floats(G, n_loc, self.n_components, self.n_covariate_components, cov_levels)
+                block = torch.zeros(nfl, dtype=torch.float32, device=f"cuda:{dev_index}")
+                kw.update(stream=torch.cuda.current_stream().cuda_stream, reduce_block=block.data_ptr())
+        eng = _native.NativeShard(**kw)
+        try:
+            chunk = max(1, (1 << 28) // (4 * G))
+            for r0 in range(c0, c1, chunk):
+                r1 = min(c1, r0 + chunk)
+                eng.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r1], dtype=np.float32), _native.X_CELLS_BY_GENES, r0 - c0)
+            eng.finalize_X()
+            for i, y in enumerate(Y):
+                eng.upload_Y(i, np.ascontiguousarray(y[c0:c1].T))
+            eng.set_factors(W0, H0, B0, h_col0=c0)
+            if sharded:
+                ShardedLoop(eng, TorchDistComm(block)).run(n_iter, with_loss=True)
+            else:
+                eng.run(n_iter, with_loss=True)
+            if scale:
+                eng.scale()
+            W, H_loc, Bs = eng.get_factors()
+            losses = eng.losses()
+            info = eng.info()
+            info_d = {f: getattr(info, f) for f, _ in info._fields_}
+        finally:
+            eng.close()
+        if sharded:
+            H = np.empty((self.total_components, N_total), dtype=np.float32)
+            parts = [None] * world
+            dist.all_gather_object(parts, (c0, c1, H_loc))
+            for a, b, h in parts:
+                H[:, a:b] = h
+        else:
+            H = H_loc
+        colnames = ["total loss", "reconstruction loss"] + [f"prediction loss({k})" for k in self.covariate_keys]
+        return dict(W=W, H=H, Bs=Bs, loss_history=pd.DataFrame(losses, columns=colnames), info=info_d)
+
+    # ------------------------------------------------- store_embeddings (main.py:303-320)
+    def store_embeddings(self, adata) -> None:
+        if not hasattr(self, "matrices"):
+            raise RuntimeError("Model is not trained yet. Please fit the model first.")
+        elif not is_anndata(adata):
+            raise TypeError("adata must be an AnnData object.")
+        adata.obsm["ALPINE_embedding"] = copy(self.matrices["Hs"][-1].T)
+        adata.varm["ALPINE_weights"] = copy(self.matrices["Ws"][-1])
+        dummy_matrices = self.fe.transform(adata.obs)
+        for i, covariate in enumerate(self.covariate_keys):
+            adata.obsm[covariate] = copy(self.matrices["Hs"][i].T)
+            adata.obsm[f"{covariate}_dummy_matrix"] = dummy_matrices[i]
+            adata.varm[covariate] = copy(self.matrices["Ws"][i])
+
+    def get_decomposed_matrices(self):
+        """main.py:238-244."""
+        if not hasattr(self, "matrices"):
+            raise RuntimeError("Model is not trained yet. Please fit the model first.")
+        return self.matrices
+
+    # -------------------------------------------------- warm-up elbow (main.py:755-770)
+    def _compute_best_iter(self, train_loss) -> int:
+        try:
+            from kneed import KneeLocator
+        except ImportError as e:  # the reference cannot even be imported without kneed
+            raise ImportError("fit(max_iter=None) needs the 'kneed' package for the Kneedle elbow (main.py:758); "
+                              "pass max_iter explicitly") from e
+        import warnings
+        kneedle = KneeLocator(np.arange(0, len(train_loss)), np.log10(train_loss), curve="convex",
+                              direction="decreasing", interp_method="polynomial", polynomial_degree=2)
+        if kneedle.elbow is not None:
+            return int(kneedle.elbow)
+        warnings.warn("Kneedle elbow not found, using default max_iter=200")
+        return 200
+
+    # ------------------------------------------------ validators (main.py:322-381, :383-434)
+    def _validate_init_args(self) -> None:
+        if self.n_components <= 0:
+            raise ValueError("n_components must be greater than 0.")
+        if not isinstance(self.n_covariate_components, list):
+            raise TypeError("n_covariate_components must be a list.")
+        for n in self.n_covariate_components:
+            if not isinstance(n, int) or n < 0:
+                raise ValueError("Each element in n_covariate_components must be a non-negative integer.")
+        if not isinstance(self.lam, list):
+            raise TypeError("lam must be in a list.")
+        for lam in self.lam:
+            if not isinstance(lam, float) or lam < 0:
+                raise ValueError("Each element in lam must be a non-negative float.")
+        if not isinstance(self.alpha_W, float) or self.alpha_W < 0:
+            raise ValueError("alpha_W must be a non-negative float.")
+        if not isinstance(self.orth_W, float) or self.orth_W < 0:
+            raise ValueError("orth_W must be a non-negative float.")
+        if not isinstance(self.l1_ratio_W, float) or self.l1_ratio_W < 0 or self.l1_ratio_W > 1:
+            raise ValueError("l1_ratio_W must be a float between 0 and 1.")
+        if not isinstance(self.scale_needed, bool):
+            raise TypeError("scale_needed must be a boolean.")
+        if not isinstance(self.loss_type, str):
+            raise TypeError("loss_type must be a string.")
+        valid_loss_types = ["kl-divergence", "frobenius"]
+        if self.loss_type not in valid_loss_types:
+            raise ValueError(f"loss_type must be one of {valid_loss_types}.")
+        if not isinstance(self.eps, float) or self.eps < 0:
+            raise ValueError("eps must be a non-negative float.")
+        if not isinstance(self.random_state, int) or self.random_state < 0:
+            raise ValueError("random_state must be a non-negative integer.")
+
+    def _validate_fit_args(self, adata, covariate_keys, batch_size, max_iter, sampling_method, verbose) -> None:
+        if not is_anndata(adata):
+            raise TypeError("adata must be an AnnData object.")
+        if not isinstance(adata.X, np.ndarray):
+            raise TypeError("adata.X must be a numpy array.")
+        elif adata.X.ndim != 2:
+            raise ValueError("adata.X must be a 2D numpy array.")
+        elif not np.all(adata.X >= 0):
+            raise ValueError("All elements in adata.X must be non-negative.")
+        if not isinstance(covariate_keys, list):
+            raise TypeError("covariate_keys must be a list.")
+        elif not len(covariate_keys) == len(self.n_covariate_components):
+            raise ValueError("Length of covariate_keys must match length of n_covariate_components.")
+        else:
+            for key in covariate_keys:
+                if not isinstance(key, str):
+                    raise TypeError("Each element in covariate_keys must be a string.")
+                if key not in adata.obs.columns:
+                    raise ValueError(f"Covariate key '{key}' not found in adata.obs.")
+                if not adata.obs[key].dtype.kind == "O":
+                    raise TypeError(f"Covariate '{key}' in adata.obs must be a categorical or object type variable.")
+        # the next two reproduce the reference's (ineffective for ints) conditions, main.py:420-428
+        if batch_size is not None and not isinstance(batch_size, int) and batch_size > 0:
+            raise TypeError("batch_size must be a positive integer.")
+        if max_iter is not None and not isinstance(max_iter, int) and max_iter > 0:
+            raise TypeError("max_iter must be a positive integer.")
+        if not isinstance(sampling_method, str):
+            raise TypeError("sampling_method must be a string.")
+        if not isinstance(verbose, bool):
+            raise TypeError("verbose must be a boolean.")

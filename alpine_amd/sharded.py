@@ -1,0 +1,52 @@
+"""Cell-axis sharding of the MU loop over the GPUs of one node: one process per GPU, one
+all-reduce (sum) of the packed reduce block per iteration over RCCL/xGMI.
+
+Everything an iteration needs from OTHER shards is a sum over cells of quantities of the old H
+(XH^T, HH^T, the B-update sums, the prediction-loss sums, ||X||^2); the engine writes its local
+sums into one contiguous float32 block in ``iter_begin``; after the all-reduce every rank holds
+the global sums and ``iter_end`` updates the replicated W, B and the local columns of H with no
+further communication.  The reference has no counterpart (single device, main.py:70).
+
+``ShardedLoop`` only orchestrates; the engine is ``_native.NativeShard`` in production.  Tests
+drive the same loop with a CPU engine over gloo to cover the N>1 logic without GPUs.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous cell block [N*r/P, N*(r+1)/P) of rank r."""
+    return (n_total * rank) // world, (n_total * (rank + 1)) // world
+
+
+class TorchDistComm:
+    """Sum-all-reduce of a torch tensor that aliases the engine's reduce block.  With the nccl
+    backend (= RCCL on ROCm) the collective is enqueued relative to the current torch stream,
+    which is the stream the engine was created on, so no host synchronisation is needed."""
+
+    def __init__(self, block, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.block = block
+        self.group = group
+
+    def all_reduce(self) -> None:
+        self._dist.all_reduce(self.block, op=self._dist.ReduceOp.SUM, group=self.group)
+
+
+class ShardedLoop:
+    def __init__(self, engine, comm):
+        self.engine = engine
+        self.comm = comm
+
+    def step(self, update: bool = True) -> None:
+        self.engine.iter_begin()
+        self.comm.all_reduce()
+        self.engine.iter_end(update)
+
+    def run(self, n_iters: int, with_loss: bool = True) -> None:
+        for _ in range(n_iters):
+            self.step(True)
+        if with_loss and n_iters > 0:
+            self.step(False)        # loss row of the last iteration needs the sums of the final H

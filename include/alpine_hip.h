@@ -1,0 +1,160 @@
+/*
+ * alpine_hip.h -- C ABI of libalpine_hip.so: the MI355X (gfx950) implementation of ALPINE's
+ * full-batch multiplicative-update NMF fit loop.
+ *
+ * The reference (ylaboratory/ALPINE v0.2.0) has no FFI/plugin seam of its own: the path sits
+ * behind a Python class whose only backend selector is `device` (alpine/main.py:58,70).  This
+ * header therefore defines the seam a maintainer binds with ctypes (INTEGRATION.md shows the
+ * stub): each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.
+ *  - every call returns 0 on success or a negative alpine_status; the text of the failure is
+ *    retrievable with alpine_last_error(ctx) (or alpine_last_error(NULL) when alpine_create
+ *    itself failed).  Nothing throws or aborts across the boundary.
+ *  - host buffers are borrowed for the duration of the call only; the library owns all device
+ *    memory except an optional caller-provided reduce block (see alpine_config).
+ *  - one ctx = one GPU = one shard of the cell axis; a ctx is driven by one host thread.
+ *  - all matrices are float32.  Host-side shapes follow the reference: W is G x K, H is K x N,
+ *    B_i is C_i x k_i, Y_i is C_i x N (alpine/main.py:28-34, :446-449), row-major, with the K
+ *    columns ordered [cov_1 | ... | cov_C | unguided] (main.py:79).
+ */
+#ifndef ALPINE_HIP_H
+#define ALPINE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALPINE_HIP_ABI_VERSION 1
+
+typedef struct alpine_ctx alpine_ctx;
+
+typedef enum {
+    ALPINE_OK = 0,
+    ALPINE_ERR_BAD_ARG = -1,
+    ALPINE_ERR_HIP = -2,
+    ALPINE_ERR_OOM = -3,
+    ALPINE_ERR_STATE = -4,     /* call made in the wrong order (e.g. run before X / factors set) */
+    ALPINE_ERR_UNSUPPORTED = -5
+} alpine_status;
+
+enum { ALPINE_LOSS_KL = 0, ALPINE_LOSS_FROBENIUS = 1 };      /* main.py:57, :371 */
+enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
+
+/* Constructor arguments of ALPINE (main.py:47-61) plus the shard geometry. */
+typedef struct {
+    int32_t struct_size;            /* sizeof(alpine_config), for ABI checking */
+    int32_t device_id;              /* HIP device ordinal */
+    int64_t n_genes;                /* G */
+    int64_t n_cells;                /* N held by THIS ctx (the local shard of the cell axis) */
+    int32_t n_components;           /* unguided K_u            (main.py:49) */
+    int32_t n_covariates;           /* C = len(covariate_keys) (main.py:50) */
+    const int32_t* cov_components;  /* k_i, length C           (main.py:50) */
+    const int32_t* cov_levels;      /* C_i = rows of Y_i, length C (encoder.py:31) */
+    const double* lam;              /* lambda_i, length C      (main.py:51) */
+    double orth_W;                  /* main.py:52 */
+    double alpha_W;                 /* main.py:53 */
+    double l1_ratio_W;              /* main.py:54 */
+    double eps;                     /* main.py:59 */
+    int32_t loss_type;              /* ALPINE_LOSS_*           (main.py:57) */
+    int32_t split_a;                /* #partial slabs of the XH^T sweep, 0 = choose */
+    int32_t split_b;                /* #partial slabs of the W^TX sweep, 0 = choose */
+    int32_t flags;                  /* reserved, 0 */
+    void* stream;                   /* hipStream_t to enqueue on, NULL = the library creates one */
+    void* reduce_block;             /* optional device buffer of alpine_reduce_block_floats() floats that the
+                                       caller owns (e.g. a torch tensor it will all-reduce); NULL = library allocates */
+} alpine_config;
+
+typedef struct {
+    int32_t abi_version;
+    int32_t k_total;                /* K = sum(k_i) + K_u */
+    int32_t k_padded;               /* KP: K rounded up to a multiple of 32 (one MFMA tile) */
+    int32_t split_a, split_b;       /* slabs actually used */
+    int32_t grid_a, grid_b;         /* workgroups of the two sweeps */
+    int64_t genes_padded, cells_padded;   /* leading dimensions of the two resident copies of X */
+    int64_t reduce_block_floats;
+    int64_t device_bytes;           /* total device memory held by the ctx */
+    double x_sqnorm;                /* ||X_local||_F^2 (valid after alpine_finalize_X) */
+} alpine_info;
+
+/* Number of floats in the per-iteration reduce block for a configuration (so a caller can allocate
+ * it before alpine_create).  Returns <0 on bad arguments. */
+int64_t alpine_reduce_block_floats(const alpine_config* cfg);
+
+/* Replaces: device selection + tensor construction of ALPINE._initialize_matrices (main.py:445-470). */
+int alpine_create(const alpine_config* cfg, alpine_ctx** out);
+int alpine_destroy(alpine_ctx* ctx);
+const char* alpine_last_error(const alpine_ctx* ctx);
+int alpine_get_info(alpine_ctx* ctx, alpine_info* info);
+
+/* Replaces `torch.tensor(X_array, device=...)` (main.py:445).  X arrives in cell chunks
+ * [cell0, cell0+n_cells) of the LOCAL shard, in either layout, from host or device memory
+ * (ld = elements between consecutive rows of the given chunk).  Both resident copies of X
+ * (genes x cells for the W^TX sweep, cells x genes for the XH^T sweep) are written. */
+int alpine_upload_X_host(alpine_ctx* ctx, const float* host, int layout, int64_t ld, int64_t cell0, int64_t n_cells);
+int alpine_upload_X_device(alpine_ctx* ctx, const float* dev, int layout, int64_t ld, int64_t cell0, int64_t n_cells);
+/* After the last chunk: computes ||X_local||^2 (used by the trace-form loss, replaces nothing). */
+int alpine_finalize_X(alpine_ctx* ctx);
+
+/* Replaces `torch.tensor(y.T, device=...)` (main.py:446-449).  host: C_i x n_cells_local, row stride ld. */
+int alpine_upload_Y(alpine_ctx* ctx, int cov, const float* host, int64_t ld);
+
+/* Replaces the torch.rand draws' destination (main.py:454-470): the caller draws on the host in
+ * the reference's order and hands the factors over.  H is K x N_local with row stride ldH (so a
+ * shard can point into a K x N_total matrix).  B = array of C pointers, B[i] is C_i x k_i. */
+int alpine_set_factors(alpine_ctx* ctx, const float* W, const float* H, int64_t ldH, const float* const* B);
+/* Replaces AlpineMatrices.to_numpy (main.py:36-43) for W, H, B (X and Y stay with the caller). */
+int alpine_get_factors(alpine_ctx* ctx, float* W, float* H, int64_t ldH, float* const* B);
+
+/* One MU iteration (main.py:589-663 + :666) split at the only point where shards exchange data:
+ *   alpine_iter_begin : sums over LOCAL cells of everything that depends on the old H
+ *                       (XH^T, HH^T, B-update sums, prediction-loss sums) -> reduce block
+ *   [ multi-GPU: the caller all-reduces (sum) the reduce block on the ctx stream ]
+ *   alpine_iter_end   : finalises the previous iteration's loss row, then W update (main.py:596-605),
+ *                       B updates (:615-628), W^TW, W^TX sweep and H update (:631-663).
+ *                       update=0 only finalises the pending loss row (used once after the last iteration).
+ * Asynchronous: work is enqueued on the ctx stream. */
+int alpine_iter_begin(alpine_ctx* ctx);
+int alpine_iter_end(alpine_ctx* ctx, int update);
+int alpine_reduce_block(alpine_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+
+/* Replaces the loop of ALPINE._fit for one device (main.py:500-667): n_iters iterations; with_loss!=0
+ * also produces one loss row per iteration ([total, recon, pred_1..pred_C], main.py:726-753). */
+int alpine_run(alpine_ctx* ctx, int n_iters, int with_loss);
+/* Loss rows accumulated so far (float64, n_rows x (C+2)); synchronises the stream. */
+int alpine_get_losses(alpine_ctx* ctx, double* rows, int64_t max_rows, int64_t* n_rows);
+int alpine_reset_losses(alpine_ctx* ctx);
+
+/* Replaces ALPINE._scale_matrices (main.py:772-781). */
+int alpine_scale(alpine_ctx* ctx);
+
+int alpine_synchronize(alpine_ctx* ctx);
+
+/* Validation helper ("common evaluator"): direct-form ||X_local - W H_local||_F^2 with
+ * float64 accumulation.  Synchronises. */
+int alpine_eval_recon_direct(alpine_ctx* ctx, double* out);
+
+/* Measurement: when enabled, hipEvents bracket every launch of the two streaming sweeps. */
+enum { ALPINE_KERNEL_SWEEP_XHT = 0, ALPINE_KERNEL_SWEEP_WTX = 1, ALPINE_KERNEL_COUNT = 2 };
+int alpine_set_profiling(alpine_ctx* ctx, int enabled);
+int alpine_get_kernel_time(alpine_ctx* ctx, int which, double* total_ms, int64_t* launches);
+
+/* Debug/test access to device-resident intermediates (synchronises): copies n floats starting at
+ * element `offset` of the named buffer to host. */
+enum {
+    ALPINE_BUF_REDUCE_BLOCK = 0,   /* [XH^T: genes_padded x KP | HH^T: KP x KP | covariate sums | ||X||^2 hi,lo] */
+    ALPINE_BUF_WTW = 1,            /* KP x KP */
+    ALPINE_BUF_W = 2,              /* genes_padded x KP, gene-major */
+    ALPINE_BUF_H = 3,              /* cells_padded x KP, cell-major */
+    ALPINE_BUF_X_GENES_BY_CELLS = 4,
+    ALPINE_BUF_X_CELLS_BY_GENES = 5
+};
+int alpine_read_buffer(alpine_ctx* ctx, int which, int64_t offset, int64_t n, float* host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALPINE_HIP_H */
