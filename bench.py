@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- NMF update iterations / second of the ALPINE MU fit loop on MI355X.
+
+A "step" is one full-batch multiplicative-update iteration (W, every B_i, H; alpine/main.py:589-663)
+INCLUDING its loss row (main.py:666) over one synthetic gene x cell matrix that is already resident
+in HBM when the timed region starts.  Workload at every GPU count = BASELINE.json's metric shape,
+"cfg3" of SURVEY.md 8d: 20 000 genes x 200 000 cells, K = 50 + [5, 5], 2 two-level covariates,
+lam = [1e3, 1e3], alpha_W = 1.0, orth_W = 0.1, l1_ratio_W = 0.5, KL loss, fp32.  With N GPUs the
+cell axis is sharded (one process per GPU, one RCCL all-reduce per iteration): strong scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the repo's driver contract) with two extra objects:
+  roofline     -- the dominant kernel (the MFMA streaming sweep, 2 launches/iteration): algorithmic
+                  flops per launch / average launch time measured live with hipEvents on the
+                  kernel's stream, against the fp32 MFMA peak (K >= 40 => MFMA-bound)
+  cpu_baseline -- the oracle's faithful torch-CPU restatement of the reference loop timed on this
+                  host's cores on a bounded sample (fewer cells), extrapolated linearly in cells
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBPS = 8000.0
+
+WORKLOADS = {
+    # name: genes, cells, K_u, k_i, alpha, orth, l1
+    "cfg2": dict(genes=20000, cells=50000, ku=50, kcov=[5], alpha_W=0.0, orth_W=0.0, l1_ratio_W=0.0),
+    "cfg3": dict(genes=20000, cells=200000, ku=50, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
+    "cfg4": dict(genes=20000, cells=1000000, ku=100, kcov=[5], alpha_W=0.0, orth_W=0.0, l1_ratio_W=0.0),
+    "tiny": dict(genes=2000, cells=5000, ku=20, kcov=[2], alpha_W=0.0, orth_W=0.0, l1_ratio_W=0.0),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cells", type=int, default=None, help="override the number of cells")
+    ap.add_argument("--genes", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loss", action="store_true", help="updates only (secondary number)")
+    ap.add_argument("--cpu-sample-cells", type=int, default=6000)
+    ap.add_argument("--split-a", type=int, default=0)
+    ap.add_argument("--split-b", type=int, default=0)
+    return ap.parse_args()
+
+
+def labels_onehot(n_cells: int, seed: int) -> np.ndarray:
+    """2 x N float32 one-hot of an i.i.d. p=0.5 two-level covariate."""
+    rng = np.random.default_rng(seed)
+    lab = rng.integers(0, 2, size=n_cells)
+    Y = np.zeros((2, n_cells), dtype=np.float32)
+    Y[lab, np.arange(n_cells)] = 1.0
+    return Y
+
+
+def cpu_baseline(wl: dict, sample_cells: int, full_cells: int) -> dict:
+    """Oracle (faithful restatement of main.py:500-667 incl. randperm gather and per-iteration loss)
+    on torch-CPU, all host cores, on `sample_cells` cells of the same workload."""
+    import torch
+    from alpine_amd.datasets import synth_counts_host
+    from oracle import alpine_oracle as orc
+    G, ku, kcov = wl["genes"], wl["ku"], wl["kcov"]
+    X = synth_counts_host(sample_cells, G, rank=ku, seed=0)
+    Ys = [labels_onehot(sample_cells, seed=1 + i).T for i in range(len(kcov))]       # N x C
+    p = orc.OracleParams(n_components=ku, n_covariate_components=list(kcov), lam=[1e3] * len(kcov),
+                         orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"])
+    s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
+    orc.fit_faithful(p, s, 1)                       # warm-up
+    n_it = 3
+    t0 = time.perf_counter()
+    orc.fit_faithful(p, s, n_it)
+    dt = time.perf_counter() - t0
+    it_s_sample = n_it / dt
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": it_s_sample * sample_cells / full_cells,
+        "unit": "iterations/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": (f"oracle.fit_faithful (torch-CPU fp32 restatement of alpine/main.py:500-667 incl. randperm gather and "
+                   f"per-iteration loss), {G} genes x {sample_cells} cells of the same synthetic workload, {n_it} timed "
+                   f"iterations after 1 warm-up = {dt:.1f} s; measured {it_s_sample:.4f} it/s on the sample, scaled linearly "
+                   f"in cells to {full_cells} (conservative: the reference scales super-linearly, BASELINE.md section 2)"),
+        "measured_sample_it_per_s": it_s_sample,
+        "host_cpu": cpu_model, "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
+    }
+
+
+def pmc_traffic(workload: str, world: int, kp: int):
+    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (collected in separate
+    runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md); None when no matching profile exists."""
+    import glob
+    if world != 1:
+        return None
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", f"{workload}_stream_gemm_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("kernel", "").endswith(f"<{kp // 32}>"):
+                best = {"bytes_per_launch": d["traffic_bytes_per_launch"], "over_algorithmic": d["traffic_over_algorithmic"],
+                        "source": os.path.relpath(f, REPO)}
+        except (OSError, ValueError, KeyError):
+            pass
+    return best
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from alpine_amd import _native
+    from alpine_amd.datasets import synth_counts_device_chunks
+    from alpine_amd.model import draw_initial_factors
+    from alpine_amd.sharded import ShardedLoop, TorchDistComm, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.cells:
+        wl["cells"] = args.cells
+    if args.genes:
+        wl["genes"] = args.genes
+    G, N, ku, kcov = wl["genes"], wl["cells"], wl["ku"], wl["kcov"]
+    K = ku + sum(kcov)
+    c0, c1 = shard_bounds(N, world, rank)
+    n_loc = c1 - c0
+    lam = [1e3] * len(kcov)
+    levels = [2] * len(kcov)
+
+    kw = dict(n_genes=G, n_cells=n_loc, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
+              orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], eps=1e-6,
+              loss_type="kl-divergence", device_id=local_rank, split_a=args.split_a, split_b=args.split_b)
+    block = None
+    if world > 1:
+        nfl = _native.reduce_block_floats(G, n_loc, ku, kcov, levels)
+        block = torch.zeros(nfl, dtype=torch.float32, device=dev)
+        kw.update(stream=torch.cuda.current_stream().cuda_stream, reduce_block=block.data_ptr())
+    eng = _native.NativeShard(**kw)
+
+    # ---- synthetic input, generated on the device in cell chunks (never on the host)
+    t_gen = time.perf_counter()
+    for off, chunk in synth_counts_device_chunks(n_loc, G, rank=ku, seed=0, device=dev, chunk_cells=16384, cell_offset=c0):
+        torch.cuda.synchronize()
+        eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
+        eng.synchronize()
+        del chunk
+    eng.finalize_X()
+    torch.cuda.empty_cache()
+    for i in range(len(kcov)):
+        eng.upload_Y(i, np.ascontiguousarray(labels_onehot(N, seed=1 + i)[:, c0:c1]))
+    W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], levels)
+    eng.set_factors(W0, H0, B0, h_col0=c0)
+    t_gen = time.perf_counter() - t_gen
+    info = eng.info()
+
+    loop = ShardedLoop(eng, TorchDistComm(block)) if world > 1 else None
+    with_loss = not args.no_loss
+
+    def run(n):
+        if loop is not None:
+            loop.run(n, with_loss=with_loss)
+        else:
+            eng.run(n, with_loss=with_loss)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    eng.reset_losses()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    run(args.steps)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fence()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_a, n_a = eng.kernel_time(_native.KERNEL_SWEEP_XHT)
+    ms_b, n_b = eng.kernel_time(_native.KERNEL_SWEEP_WTX)
+    losses = eng.losses()
+    eng.set_profiling(False)
+
+    if rank == 0:
+        it_s = args.steps / dt
+        launches = n_a + n_b
+        avg_ms = (ms_a + ms_b) / max(1, launches)
+        flops_per_launch = 2.0 * G * n_loc * K                    # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
+        bytes_per_launch = 4.0 * G * n_loc                        # X read once per sweep
+        ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "NMF update iterations/sec (20k genes x 200k cells, K=50)",
+            "value": it_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": (f"{args.workload}: {G} genes x {N} cells, K={ku}+{kcov} (K={K}), {len(kcov)} two-level covariates, "
+                             f"lam=1e3, alpha_W={wl['alpha_W']}, orth_W={wl['orth_W']}, l1_ratio_W={wl['l1_ratio_W']}, KL loss, "
+                             f"full batch, loss row every iteration={with_loss}; X ~ Poisson(Gamma(0.3)xGamma(0.3)), mean~1"),
+                "cells_per_gpu": n_loc, "k_padded": info.k_padded, "split_xht": info.split_a, "split_wtx": info.split_b,
+                "grid_xht": info.grid_a, "grid_wtx": info.grid_b, "device_GiB": round(info.device_bytes / 2**30, 2),
+                "parallelism": f"cells/{world}",
+            },
+            "roofline": {
+                "kernel": "stream_gemm_kernel (MFMA f32 32x32x2; XH^T and W^TX sweeps)",
+                "bound": "mfma", "achieved": ach_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": (pmc_traffic(args.workload, world, info.k_padded) or {}).get("bytes_per_launch") if not (args.cells or args.genes) else None,
+                "traffic_detail": pmc_traffic(args.workload, world, info.k_padded) if not (args.cells or args.genes) else None,
+                "avg_launch_ms": avg_ms, "launches": launches,
+                "avg_ms_xht": ms_a / max(1, n_a), "avg_ms_wtx": ms_b / max(1, n_b),
+                "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "hbm_achieved_GBps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                "hbm_frac_of_8TBps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if avg_ms > 0 else 0.0,
+                "sweeps_share_of_step": (ms_a + ms_b) / (1e3 * dt) if dt > 0 else 0.0,
+            },
+            "final_loss_row": losses[-1].tolist() if len(losses) else None,
+            "setup_s": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample_cells, N), N)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+"""CPU tests (no GPU): host-side mirror of the reference API, ingest helpers, and that the C-ABI
+library loads and exports every symbol include/alpine_hip.h declares (no compute calls)."""
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from _golden import ALL_CASES, SMALL_CASES, load_case
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from alpine_amd import _native
+    from alpine_amd.build import build_library
+    build_library()                                  # hipcc cross-compiles gfx950 without a GPU
+    lib = _native.load()
+    header = open(os.path.join(REPO, "include", "alpine_hip.h")).read()
+    declared = set(re.findall(r"\b(alpine_[a-z_A-Z0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_native.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_config_struct_matches_header_size():
+    from alpine_amd import _native
+    import ctypes as C
+    # struct_size mismatch is how the library detects ABI drift; a bad size must be refused loudly
+    cfg = _native.AlpineConfig()
+    cfg.struct_size = C.sizeof(_native.AlpineConfig) - 4
+    assert _native.load().alpine_reduce_block_floats(C.byref(cfg)) < 0
+    n = _native.reduce_block_floats(20000, 200000, 50, [5, 5], [2, 2])
+    assert n == 20096 * 64 + 64 * 64 + 2 * (2 * 5 + 5 + 2) + 2     # XH^T | HH^T | cov sums | ||X||^2 hi,lo
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from alpine_amd import ALPINE, MiniAnnData, _native
+    with pytest.raises(_native.AlpineNativeError):
+        _native.NativeShard(64, 96, 4, [2], [2], [1.0])
+    c = load_case("kl_1cov")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ALPINE(device="cuda", **c.params).fit(MiniAnnData(c.X, c.obs), covariate_keys=c.keys, max_iter=2)
+    with pytest.raises(ValueError, match="no CPU path"):
+        ALPINE(device="cpu", **c.params).fit(MiniAnnData(c.X, c.obs), covariate_keys=c.keys, max_iter=2)
+
+
+def test_product_package_does_not_import_oracle():
+    import ast
+    pkg = os.path.join(REPO, "alpine_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            tree = ast.parse(open(os.path.join(pkg, fn)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                assert not any(n.split(".")[0] == "oracle" for n in names), f"{fn} imports the oracle"
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_initial_draws_match_reference_bitwise(name):
+    from alpine_amd.model import draw_initial_factors
+    c = load_case(name)
+    p = c.params
+    n_all = p["n_covariate_components"] + [p["n_components"]]
+    W0, H0, B0 = draw_initial_factors(p.get("random_state", 42), p.get("eps", 1e-6), c.X.shape[1], c.X.shape[0], n_all,
+                                      [y.shape[0] for y in c.Ys])
+    assert np.array_equal(W0, c.W0) and np.array_equal(H0, c.H0)
+    for b, b0 in zip(B0, c.B0):
+        assert np.array_equal(b, b0)
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_encoder_matches_reference(name):
+    from alpine_amd.encoder import FeatureEncoders
+    c = load_case(name)
+    fe = FeatureEncoders(c.keys)
+    Y = fe.fit_transform(c.obs)
+    for y, want in zip(Y, c.Ys):
+        assert y.dtype == np.float32 and np.array_equal(y, want.T)
+    assert fe.encoded_labels == c.meta["encoded_labels"]
+    for y, y2 in zip(Y, fe.transform(c.obs)):
+        assert np.array_equal(y, y2)
+
+
+def test_encoder_nan_and_unknown_rows_are_zero():
+    from alpine_amd.encoder import FeatureEncoders
+    df = pd.DataFrame({"c": np.array(["b", np.nan, "a", None, "b"], dtype=object)})
+    fe = FeatureEncoders(["c"])
+    Y = fe.fit_transform(df)[0]
+    assert Y.tolist() == [[0, 1], [0, 0], [1, 0], [0, 0], [0, 1]]
+    assert fe.encoded_labels["c"] == ["c_a", "c_b"]
+    Y2 = fe.transform(pd.DataFrame({"c": np.array(["zzz", "a"], dtype=object)}))[0]
+    assert Y2.tolist() == [[0, 0], [1, 0]]
+    with pytest.raises(TypeError):
+        fe.fit_transform([1, 2, 3])
+
+
+# ---- validators: same exceptions and messages as alpine/main.py:322-381, :383-434
+GOOD = dict(n_components=4, n_covariate_components=[2], lam=[1.0])
+
+
+@pytest.mark.parametrize("kw,exc,msg", [
+    (dict(n_components=0), ValueError, "n_components must be greater than 0."),
+    (dict(n_covariate_components=(2,)), TypeError, "n_covariate_components must be a list."),
+    (dict(n_covariate_components=[-1]), ValueError, "Each element in n_covariate_components must be a non-negative integer."),
+    (dict(lam=(1.0,)), TypeError, "lam must be in a list."),
+    (dict(lam=[1]), ValueError, "Each element in lam must be a non-negative float."),       # int rejected (main.py:342)
+    (dict(alpha_W=0), ValueError, "alpha_W must be a non-negative float."),                 # README's own example raises
+    (dict(orth_W=-0.1), ValueError, "orth_W must be a non-negative float."),
+    (dict(l1_ratio_W=1.5), ValueError, "l1_ratio_W must be a float between 0 and 1."),
+    (dict(scale_needed=1), TypeError, "scale_needed must be a boolean."),
+    (dict(loss_type=3), TypeError, "loss_type must be a string."),
+    (dict(loss_type="l2"), ValueError, "loss_type must be one of ['kl-divergence', 'frobenius']."),
+    (dict(eps=0), ValueError, "eps must be a non-negative float."),
+    (dict(random_state=-1), ValueError, "random_state must be a non-negative integer."),
+])
+def test_init_validation(kw, exc, msg):
+    from alpine_amd import ALPINE
+    with pytest.raises(exc) as e:
+        ALPINE(**{**GOOD, **kw})
+    assert str(e.value) == msg
+
+
+def test_init_attributes():
+    from alpine_amd import ALPINE
+    m = ALPINE(n_components=30, n_covariate_components=[5, 5], lam=[1e3, 1e3])
+    assert m.n_all_components == [5, 5, 30] and m.total_components == 40
+    assert m.device.type == "cuda" and m.loss_type == "kl-divergence" and m.scale_needed is True
+    with pytest.raises(RuntimeError, match="Model is not trained yet"):
+        m.store_embeddings(object())
+
+
+def _adata(n=20, g=8):
+    from alpine_amd import MiniAnnData
+    rng = np.random.default_rng(0)
+    return MiniAnnData(rng.random((n, g)).astype(np.float32), pd.DataFrame({"c": rng.choice(["a", "b"], n).astype(object),
+                                                                            "num": np.arange(n)}))
+
+
+@pytest.mark.parametrize("mutate,keys,exc,msg", [
+    (lambda a: None, "c", TypeError, "covariate_keys must be a list."),
+    (lambda a: None, ["c", "d"], ValueError, "Length of covariate_keys must match length of n_covariate_components."),
+    (lambda a: None, [3], TypeError, "Each element in covariate_keys must be a string."),
+    (lambda a: None, ["missing"], ValueError, "Covariate key 'missing' not found in adata.obs."),
+    (lambda a: None, ["num"], TypeError, "Covariate 'num' in adata.obs must be a categorical or object type variable."),
+    (lambda a: setattr(a, "X", a.X.tolist()), ["c"], TypeError, "adata.X must be a numpy array."),
+    (lambda a: setattr(a, "X", a.X[0]), ["c"], ValueError, "adata.X must be a 2D numpy array."),
+    (lambda a: setattr(a, "X", -a.X), ["c"], ValueError, "All elements in adata.X must be non-negative."),
+])
+def test_fit_validation(mutate, keys, exc, msg):
+    from alpine_amd import ALPINE
+    a = _adata()
+    mutate(a)
+    with pytest.raises(exc) as e:
+        ALPINE(**GOOD).fit(a, covariate_keys=keys, max_iter=1)
+    assert str(e.value) == msg
+
+
+def test_fit_rejects_non_anndata_and_unsupported_modes():
+    from alpine_amd import ALPINE
+    with pytest.raises(TypeError, match="adata must be an AnnData object."):
+        ALPINE(**GOOD).fit(np.zeros((3, 3)), covariate_keys=["c"], max_iter=1)
+    a = _adata()
+    with pytest.raises(TypeError, match="sampling_method must be a string."):
+        ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, sampling_method=3)
+    with pytest.raises(TypeError, match="verbose must be a boolean."):
+        ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, verbose=1)
+    with pytest.raises(NotImplementedError):
+        ALPINE(use_als=True, **GOOD).fit(a, covariate_keys=["c"], max_iter=1)
+    with pytest.raises(NotImplementedError):
+        ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, batch_size=5)
+    with pytest.raises(ValueError, match="Unknown sampling method"):
+        ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, sampling_method="bogus")
+
+
+def test_synthetic_generator_is_count_like():
+    from alpine_amd.datasets import synth_counts_host, synth_labels_host
+    X = synth_counts_host(300, 200, rank=8, seed=1)
+    assert X.dtype == np.float32 and X.shape == (300, 200) and (X >= 0).all()
+    assert 0.5 < X.mean() < 2.0 and (X == 0).mean() > 0.5
+    assert np.array_equal(X, synth_counts_host(300, 200, rank=8, seed=1))
+    lab = synth_labels_host(50, ["a", "b"])
+    assert lab.dtype.kind == "O" and set(lab) <= {"a", "b"}
