@@ -1,0 +1,60 @@
+"""Sharded HIP path on ONE GPU box: two ranks (processes) both drive cuda:0 with the real engine
+(external reduce block in a torch tensor, engine on torch's stream), all-reduce over gloo (RCCL needs
+one device per rank; the protocol above the collective is what this covers).  Result must equal the
+single-shard HIP run to rounding, and the reference golden vectors to the stated tolerance."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case_name, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _golden import load_case
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case(case_name)
+    adata = MiniAnnData(c.X.copy(), c.obs.copy())
+    m = ALPINE(device="cuda:0", shard_cells=True, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=np.concatenate(m.matrices["Ws"], axis=1),
+             H=np.concatenate(m.matrices["Hs"], axis=0), losses=m.loss_history.to_numpy(),
+             **{f"B{i}": b for i, b in enumerate(m.matrices["Bs"])})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "ragged"])
+def test_two_ranks_one_gpu(case_name, tmp_path):
+    import torch.multiprocessing as mp
+    from _golden import assert_loss_rows_close, load_case, rel_fro
+    from alpine_amd import ALPINE, MiniAnnData
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), case_name, str(tmp_path)), nprocs=world, join=True)
+    c = load_case(case_name)
+    single = ALPINE(device="cuda:0", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
+    W1 = np.concatenate(single.matrices["Ws"], axis=1)
+    H1 = np.concatenate(single.matrices["Hs"], axis=0)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert np.array_equal(r[0]["W"], r[1]["W"]) and np.array_equal(r[0]["H"], r[1]["H"])
+    assert rel_fro(r[0]["W"], W1) < 5e-6 and rel_fro(r[0]["H"], H1) < 5e-6
+    assert rel_fro(r[0]["W"], c.WT) < 1e-4 and rel_fro(r[0]["H"], c.HT) < 1e-4
+    for i, bt in enumerate(c.BT):
+        assert rel_fro(r[0][f"B{i}"], bt) < 2e-4
+    assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
