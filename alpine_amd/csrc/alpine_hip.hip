@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,8 +33,8 @@ struct alpine_ctx {
     // device buffers
     float *Xgn = nullptr, *Xng = nullptr, *W = nullptr, *H = nullptr, *Y = nullptr, *B[2] = {nullptr, nullptr};
     int bcur = 0;
-    float *slabA = nullptr, *slabB = nullptr;
-    int splitA = 1, splitB = 1, rpsA = 0, rpsB = 0, nftA = 0, nftB = 0, gridA = 0, gridB = 0;
+    float *piecesA = nullptr, *piecesB = nullptr;     // stream-K partial results of the two sweeps
+    SweepGeom geomA{}, geomB{};
     float* red = nullptr;
     bool own_red = false;
     int64_t red_floats = 0, red_hht = 0, red_stats = 0;
@@ -56,6 +57,10 @@ struct alpine_ctx {
     std::vector<bool> y_set;
     size_t bytes = 0;
     std::string err;
+    // timing-only ablation (env ALPINE_HIP_ABLATE_STRIDE0=1): the sweeps re-read row 0 of X (served from cache) -> wrong
+    // results, prices the HBM stream against the MFMA pipeline.  Never set in tests or bench.
+    bool ablate_stride0 = false;
+    int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ALPINE_KERNEL_COUNT];
@@ -150,20 +155,21 @@ extern "C" int64_t alpine_reduce_block_floats(const alpine_config* cfg)
     return g.red_floats;
 }
 
-// Number of partial slabs for a sweep: trade the tail of the last round of workgroups against
-// the extra slab traffic (2 * s * KP / R of the streamed bytes).
-static int choose_split(int n_ftiles, int64_t R, int KP, int slots, int forced)
+// Stream-K geometry of a sweep (see SweepGeom in kernels.hpp): a fixed grid of `slots` workgroups (as many as the
+// chip holds at once), each an equal span of L rows of the (tile,row) space.  forced > 0 asks for about `forced`
+// pieces per tile instead (tests use it to exercise spans that do / do not cross tiles).
+static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced)
 {
-    if (forced > 0) return (int)std::min<int64_t>(forced, std::max<int64_t>(1, R / SG_CH));
-    double best = 1e30; int best_s = 1;
-    for (int s = 1; s <= 96; ++s) {
-        if (R / s < 512 && s > 1) break;
-        const double rounds = (double)n_ftiles * s / slots;
-        const double tail = std::ceil(rounds - 1e-9) / rounds;
-        const double cost = tail * (1.0 + 2.0 * s * KP / (double)R);
-        if (cost < best - 1e-9) { best = cost; best_s = s; }
-    }
-    return best_s;
+    SweepGeom g{};
+    g.F = (int)F; g.R = (int)R;
+    g.nft = (int)((F + SG_BLOCK_F - 1) / SG_BLOCK_F);
+    const int64_t total = (int64_t)g.nft * R;
+    int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
+    want = std::max<int64_t>(1, std::min<int64_t>(want, total / SG_ROW_ALIGN));
+    g.L = (int)round_up((total + want - 1) / want, SG_ROW_ALIGN);
+    g.nwg = (int)((total + g.L - 1) / g.L);
+    g.maxp = (int)((g.L + R - 1) / R) + 1;
+    return g;
 }
 
 // ---------------------------------------------------------------------------------- create
@@ -182,6 +188,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, ALPINE_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     c->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("ALPINE_HIP_ABLATE_STRIDE0")) c->ablate_stride0 = (e[0] == '1');
+    if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
 
@@ -203,13 +211,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
     // sweeps
     const int slots = c->n_cu * (c->KT <= 2 ? 2 : 1);
-    c->nftA = (int)((Gp + SG_BLOCK_F - 1) / SG_BLOCK_F);      // XH^T: f = genes, r = cells
-    c->nftB = (int)((Np + SG_BLOCK_F - 1) / SG_BLOCK_F);      // W^TX: f = cells, r = genes
-    int sA = choose_split(c->nftA, Np, KP, slots, cfg->split_a);
-    int sB = choose_split(c->nftB, Gp, KP, slots, cfg->split_b);
-    c->rpsA = (int)round_up((Np + sA - 1) / sA, SG_CH); c->splitA = (int)((Np + c->rpsA - 1) / c->rpsA);
-    c->rpsB = (int)round_up((Gp + sB - 1) / sB, SG_CH); c->splitB = (int)((Gp + c->rpsB - 1) / c->rpsB);
-    c->gridA = c->nftA * c->splitA; c->gridB = c->nftB * c->splitB;
+    c->geomA = make_geom(Gp, Np, slots, cfg->split_a);       // XH^T: f = genes, r = cells
+    c->geomB = make_geom(Np, Gp, slots, cfg->split_b);       // W^TX: f = cells, r = genes
 
     ALLOC(c, c->Xgn, float, Gp * Np);
     ALLOC(c, c->Xng, float, Np * Gp);
@@ -218,8 +221,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
     ALLOC(c, c->B[0], float, std::max(1, c->nB));
     ALLOC(c, c->B[1], float, std::max(1, c->nB));
-    ALLOC(c, c->slabA, float, (int64_t)c->splitA * Gp * KP);
-    ALLOC(c, c->slabB, float, (int64_t)c->splitB * Np * KP);
+    ALLOC(c, c->piecesA, float, (int64_t)c->geomA.nwg * c->geomA.maxp * SG_BLOCK_F * KP);
+    ALLOC(c, c->piecesB, float, (int64_t)c->geomB.nwg * c->geomB.maxp * SG_BLOCK_F * KP);
     c->red_floats = g.red_floats; c->red_hht = g.red_hht; c->red_stats = g.red_stats;
     if (cfg->reduce_block) { c->red = (float*)cfg->reduce_block; c->own_red = false; HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream)); }
     else { ALLOC(c, c->red, float, c->red_floats); c->own_red = true; }
@@ -267,7 +270,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->slabA, c->slabB, c->own_red ? c->red : nullptr,
+    void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
                     c->WtW, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -283,7 +286,7 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     if (!c || !info) return fail(c, ALPINE_ERR_BAD_ARG, "NULL argument");
     info->abi_version = ALPINE_HIP_ABI_VERSION;
     info->k_total = c->K; info->k_padded = c->KP;
-    info->split_a = c->splitA; info->split_b = c->splitB; info->grid_a = c->gridA; info->grid_b = c->gridB;
+    info->split_a = c->geomA.maxp; info->split_b = c->geomB.maxp; info->grid_a = c->geomA.nwg; info->grid_b = c->geomB.nwg;
     info->genes_padded = c->Gp; info->cells_padded = c->Np;
     info->reduce_block_floats = c->red_floats;
     info->device_bytes = (int64_t)c->bytes;
@@ -502,6 +505,31 @@ static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int blocks, flo
     return launch_reduce(c, c->gramPart, out, (int64_t)c->KP * c->KP, blocks * 4);
 }
 
+// the two streaming sweeps share one launcher; the variant only changes the pipeline shape, never the result
+static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces)
+{
+    const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
+#define SG_LAUNCH(RING, PASSES) \
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_kernel<KT_, RING, PASSES>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, P, pieces, ldS, g, (unsigned long long*)nullptr))
+    switch (c->sg_variant) {
+        case 1: SG_LAUNCH(8, 4); break;
+        case 2: SG_LAUNCH(8, 2); break;
+        default: SG_LAUNCH(16, 1); break;
+    }
+#undef SG_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int launch_reduce_pieces(alpine_ctx* c, const float* pieces, float* out, int rows, const SweepGeom& g)
+{
+    const int64_t n4 = (int64_t)rows * c->KP / 4;
+    const int blocks = (int)std::min<int64_t>(c->n_cu * 8, (n4 + 255) / 256);
+    hipLaunchKernelGGL(reduce_pieces_kernel, dim3(std::max(1, blocks)), dim3(256), 0, c->stream, pieces, out, rows, c->KP, g);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 static int ready(alpine_ctx* c)
 {
     if (!c) return ALPINE_ERR_BAD_ARG;
@@ -528,11 +556,9 @@ extern "C" int alpine_iter_begin(alpine_ctx* c)
     rc = launch_gram(c, c->H, c->Np, c->gramBlocksH, c->red + c->red_hht);
     if (rc) return rc;
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(stream_gemm_kernel<KT_>, dim3(c->gridA), dim3(SG_THREADS), 0, c->stream,
-                                           c->Xng, c->H, c->slabA, c->Gp, (int)c->Gp, (int)c->Np, c->rpsA, c->nftA));
-    HIPCHK(c, hipGetLastError());
+    if ((rc = launch_sweep(c, c->geomA, c->Xng, c->H, c->piecesA))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-    return launch_reduce(c, c->slabA, c->red, c->Gp * KP, c->splitA);
+    return launch_reduce_pieces(c, c->piecesA, c->red, (int)c->Gp, c->geomA);
 }
 
 static int grow_losses(alpine_ctx* c)
@@ -579,14 +605,12 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
     rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW);
     if (rc) return rc;
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(stream_gemm_kernel<KT_>, dim3(c->gridB), dim3(SG_THREADS), 0, c->stream,
-                                           c->Xgn, c->W, c->slabB, c->Np, (int)c->Np, (int)c->Gp, c->rpsB, c->nftB));
-    HIPCHK(c, hipGetLastError());
+    if ((rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
     const int hblocks = (int)((c->N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
     const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->slabB, c->splitB,
-                                           c->Np * (int64_t)KP, c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->piecesB, c->geomB,
+                                           c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
     HIPCHK(c, hipGetLastError());
     c->pending_loss = true;
     return 0;

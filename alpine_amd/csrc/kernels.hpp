@@ -58,116 +58,195 @@ struct CovMeta {
 // v_mfma_f32_32x32x2_f32: A[i=l&31][kk=l>>5] = P[r+kk][32m+i], B[kk=l>>5][j=l&31] = S[r+kk][f(j)],
 // where the four B tiles of a wave interleave along f (tile t column j is f0 + 4j + t), so that one
 // float4 load feeds four MFMAs.  Work item = (512-wide f tile, split of the r range); partial results
-// go to slab[split][f][KP] and are summed in a fixed order downstream (deterministic, no atomics).
+// go to per-workgroup pieces (stream-K, see SweepGeom) and are summed in a fixed order downstream.
 constexpr int SG_THREADS = 256;
 constexpr int SG_WAVES = 4;
 constexpr int SG_WAVE_F = 128;
 constexpr int SG_BLOCK_F = SG_WAVES * SG_WAVE_F;
-constexpr int SG_CH = 16;            // rows per pipeline stage (8 MFMA k-steps)
-constexpr int SG_NP = SG_CH / 2;
+constexpr int SG_ROW_ALIGN = 64;     // split boundaries are multiples of this (>= rows per panel stage of every variant)
 
-template <int KT>
-__device__ __forceinline__ void sg_compute(f32x16 (&acc)[KT][4], const f32x4 (&x)[SG_NP],
-                                           const float* __restrict__ lbuf, int c, int h)
+// One panel stage = SG_RING k-steps.  Software pipeline per k-step p (all indices static):
+//   ds_read  A operands of step p+1          (LDS latency hidden behind the 8..16 MFMAs of step p)
+//   8*KT/2.. MFMAs of step p on x[p]
+//   global_load x[p] <- the same k-step of the NEXT stage (prefetch distance = SG_RING k-steps, constant)
+// so the instruction stream is uniformly MFMA-dense and exactly SG_RING (+ panel) loads are always in flight.
+
+template <int KT, int SG_RING, bool LAST>
+__device__ __forceinline__ void sg_stage(f32x16 (&acc)[KT][4], f32x4 (&x)[SG_RING], const float* __restrict__ lrow,
+                                         const float* __restrict__ xnext, int64_t ldS)
 {
     constexpr int KP = 32 * KT;
+    float a[2][KT];
 #pragma unroll
-    for (int p = 0; p < SG_NP; ++p) {
-        float a[KT];
+    for (int m = 0; m < KT; ++m) a[0][m] = lrow[32 * m];
 #pragma unroll
-        for (int m = 0; m < KT; ++m) a[m] = lbuf[(2 * p + h) * KP + 32 * m + c];
+    for (int p = 0; p < SG_RING; ++p) {
+        if (p + 1 < SG_RING) {
+#pragma unroll
+            for (int m = 0; m < KT; ++m) a[(p + 1) & 1][m] = lrow[(2 * (p + 1)) * KP + 32 * m];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // LDS read of step p+1 issues BEFORE the MFMAs of step p
 #pragma unroll
         for (int m = 0; m < KT; ++m) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], x[p][j], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][m], x[p][j], acc[m][j], 0, 0, 0);
         }
+        if (!LAST) x[p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xnext + (int64_t)(2 * p) * ldS));
+        __builtin_amdgcn_sched_barrier(0);       // keep one load per k-step where it is (see kernel comment)
     }
 }
 
-template <int KT>
-__global__ __launch_bounds__(SG_THREADS, (KT <= 2 ? 2 : 1))
-void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P, float* __restrict__ slab,
-                        int64_t ldS, int F, int R, int rows_per_split, int n_ftiles)
+// Work division ("stream-K"): the (f tile, row) space of nft * R rows is cut into equal contiguous spans of L rows,
+// one per workgroup of a fixed grid (2 x #CU at K <= 64), so every workgroup executes the same number of MFMAs and
+// there is no ragged last round.  A span may cross tile boundaries; the workgroup writes one partial piece per tile
+// it touches: piece(w, j) = pieces[((w * maxp + j) * 512 + f_local) * KP + k], j = tile - first tile of w.  Consumers
+// sum a tile's pieces in ascending w (sg_tile_pieces below): fixed order, no atomics, bitwise reproducible.
+struct SweepGeom {
+    int F;        // free extent, multiple of 128 (leading dimension of S)
+    int R;        // contraction rows, multiple of SG_ROW_ALIGN
+    int nft;      // 512-wide f tiles
+    int L;        // rows of (tile,row) space per workgroup, multiple of SG_ROW_ALIGN
+    int nwg;      // workgroups
+    int maxp;     // pieces per workgroup
+};
+
+// pieces that contribute to tile ft: workgroups w_lo..w_hi; piece index of w for this tile
+__device__ __forceinline__ void sg_tile_pieces(const SweepGeom& g, int ft, int& w_lo, int& w_hi)
 {
+    w_lo = (int)(((int64_t)ft * g.R) / g.L);
+    w_hi = min(g.nwg - 1, (int)((((int64_t)ft + 1) * g.R - 1) / g.L));
+}
+__device__ __forceinline__ int64_t sg_piece_offset(const SweepGeom& g, int w, int ft, int KP)
+{
+    const int first = (int)(((int64_t)w * g.L) / g.R);
+    return ((int64_t)w * g.maxp + (ft - first)) * SG_BLOCK_F * KP;
+}
+
+// SG_RING = X register ring depth in MFMA k-steps (= prefetch distance); SG_PASSES = ring passes per panel stage
+// (one barrier per 2*SG_RING*SG_PASSES rows).
+template <int KT, int SG_RING, int SG_PASSES>
+__global__ __launch_bounds__(SG_THREADS, (KT <= 2 ? 2 : 1))
+void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P, float* __restrict__ pieces,
+                        int64_t ldS, SweepGeom g,
+                        unsigned long long* __restrict__ clk = nullptr)   // diagnostics only (tools/sweep_bench): per-WG {cycles, 100 MHz ticks, start tick, XCC id}
+{
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int KP = 32 * KT;
-    constexpr int PV = (4 * KP + SG_THREADS - 1) / SG_THREADS;   // float4 per thread per panel stage
+    constexpr int SG_CH = 2 * SG_RING * SG_PASSES;                 // rows per panel stage
+    static_assert(SG_ROW_ALIGN % SG_CH == 0, "stage rows must divide the span alignment");
+    constexpr int PASS = 2 * SG_RING;                              // rows per ring pass
+    constexpr int PV = SG_CH * KP / 4 / SG_THREADS;                // float4 per thread per panel stage
+    static_assert(SG_CH * KP / 4 % SG_THREADS == 0, "panel stage must tile the workgroup exactly");
     __shared__ __attribute__((aligned(16))) float lds[2][SG_CH * KP];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar branches
     const int c = lane & 31, h = lane >> 5;
-    const int ft = blockIdx.x % n_ftiles;
-    const int sp = blockIdx.x / n_ftiles;
-    const int f0 = (ft * SG_WAVES + wave) * SG_WAVE_F;
-    const bool active = f0 < F;
-    const int r_begin = sp * rows_per_split;
-    const int r_end = min(R, r_begin + rows_per_split);
-    const int nch = (r_end - r_begin) / SG_CH;
+    const int w = blockIdx.x;
+    const int64_t total = (int64_t)g.nft * g.R;
+    int64_t pos = (int64_t)w * g.L;
+    const int64_t pos_end = min(total, pos + g.L);
+    const int first_tile = (int)(pos / g.R);
+    const int lds_lane = h * KP + c;
 
-    f32x16 acc[KT][4];
-#pragma unroll
-    for (int m = 0; m < KT; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+    f32x4 preg[PV];
+    f32x4 x[SG_RING];
 
-    const float* sptr = S + (int64_t)(r_begin + h) * ldS + (active ? f0 : 0) + 4 * c;
-    const float* pptr = P + (int64_t)r_begin * KP;
-    const int64_t s_stage = (int64_t)SG_CH * ldS;
+    while (pos < pos_end) {
+        const int ft = (int)(pos / g.R);
+        const int r_begin = (int)(pos - (int64_t)ft * g.R);
+        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
+        pos += r_end - r_begin;
+        const int nst = (r_end - r_begin) / SG_CH;                 // >= 1 (everything is a multiple of SG_ROW_ALIGN)
+        const int f0 = (ft * SG_WAVES + wave) * SG_WAVE_F;
+        const bool active = f0 < g.F;
 
-    f32x4 xa[SG_NP], xb[SG_NP], preg[PV];
+        // panel staging through PV float4 registers per thread
+        const float* pptr = P + (int64_t)r_begin * KP + 4 * tid;
+        auto load_p = [&](int t) {
+            const float* q = pptr + (int64_t)t * (SG_CH * KP);
+#pragma unroll
+            for (int v = 0; v < PV; ++v) preg[v] = *reinterpret_cast<const f32x4*>(q + 4 * SG_THREADS * v);
+        };
+        auto store_p = [&](int b) {
+#pragma unroll
+            for (int v = 0; v < PV; ++v) *reinterpret_cast<f32x4*>(&lds[b][4 * (tid + SG_THREADS * v)]) = preg[v];
+        };
 
-    auto load_x = [&](f32x4 (&x)[SG_NP], int ci) {
-        const float* q = sptr + ci * s_stage;
-#pragma unroll
-        for (int p = 0; p < SG_NP; ++p)
-            x[p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + (int64_t)(2 * p) * ldS));
-    };
-    auto load_p = [&](int ci) {
-        const float* q = pptr + (int64_t)ci * (SG_CH * KP);
-#pragma unroll
-        for (int v = 0; v < PV; ++v) {
-            const int idx = tid + SG_THREADS * v;
-            if (idx < 4 * KP) preg[v] = *reinterpret_cast<const f32x4*>(q + 4 * idx);
-        }
-    };
-    auto store_p = [&](int b) {
-#pragma unroll
-        for (int v = 0; v < PV; ++v) {
-            const int idx = tid + SG_THREADS * v;
-            if (idx < 4 * KP) *reinterpret_cast<f32x4*>(&lds[b][4 * idx]) = preg[v];
-        }
-    };
-
-    if (nch > 0) {
+        __syncthreads();                      // previous segment's readers are done with both LDS buffers
+        // prologue in the SAME issue order as the steady state (panel loads older than the X ring), so that the
+        // vmcnt state at loop entry equals the state at the back-edge and the in-loop waits stay counted
         load_p(0);
-        if (active) load_x(xa, 0);
         store_p(0);
-        if (nch > 1) load_p(1);
+        if (nst > 1) load_p(1);
+
+        if (!active) {
+            // a wave whose f range is past the matrix only helps staging the panel; same barrier sequence
+            __syncthreads();
+            for (int t = 0; t + 1 < nst; ++t) {
+                store_p((t + 1) & 1);
+                if (t + 2 < nst) load_p(t + 2);
+                __syncthreads();
+            }
+            continue;
+        }
+
+        f32x16 acc[KT][4];
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+        // X addressing: row base advances by whole ring passes; one per-lane offset
+        const float* xrow = S + (int64_t)r_begin * ldS + (h * (int)ldS + f0 + 4 * c);   // this lane's element of row pair 0
+        const int64_t x_pass = (int64_t)PASS * ldS;
+
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < SG_RING; ++p)
+            x[p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow + (int64_t)(2 * p) * ldS));
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
 
-        // stage ci: panel ci is in lds[ci&1], its X rows are in flight/landed in xc.
-        auto stage = [&](f32x4 (&xc)[SG_NP], f32x4 (&xn)[SG_NP], int ci) {
-            const int b = ci & 1;
-            if (ci + 1 < nch) store_p(b ^ 1);          // lds[b^1] was last read in stage ci-1 (barrier since)
-            if (ci + 2 < nch) load_p(ci + 2);
-            if (active) {
-                if (ci + 1 < nch) load_x(xn, ci + 1);
-                sg_compute<KT>(acc, xc, lds[b], c, h);
-            }
+        // Steady state.  Loads in flight at any k-step: SG_RING X loads + PV panel loads, all unconditional, so the
+        // compiler's vmcnt bookkeeping is exact (constant vmcnt(SG_RING + PV - 1)); sched_barrier(0) pins the issue
+        // points -- left alone, the scheduler sinks the loads next to their first use to save registers, which
+        // serialises the HBM latency.
+        int t = 0;
+        for (; t + 2 < nst; ++t) {
+            const float* lb = &lds[t & 1][lds_lane];
+            store_p((t + 1) & 1);             // panel t+1 (loaded during stage t-1); buffer last read in stage t-1
+            load_p(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < SG_PASSES; ++q)
+                sg_stage<KT, SG_RING, false>(acc, x, lb + q * PASS * KP, xrow + (t * SG_PASSES + q + 1) * x_pass, ldS);
             __syncthreads();
-        };
-        for (int ci = 0; ci < nch; ci += 2) {
-            stage(xa, xb, ci);
-            if (ci + 1 < nch) stage(xb, xa, ci + 1);
         }
-    }
+        if (t + 1 < nst) {                    // second-to-last stage: no panel left to prefetch
+            const float* lb = &lds[t & 1][lds_lane];
+            store_p((t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < SG_PASSES; ++q)
+                sg_stage<KT, SG_RING, false>(acc, x, lb + q * PASS * KP, xrow + (t * SG_PASSES + q + 1) * x_pass, ldS);
+            __syncthreads();
+            ++t;
+        }
+        {   // last stage: only its final pass has nothing left to prefetch
+            const float* lb = &lds[t & 1][lds_lane];
+#pragma unroll
+            for (int q = 0; q < SG_PASSES - 1; ++q)
+                sg_stage<KT, SG_RING, false>(acc, x, lb + q * PASS * KP, xrow + (t * SG_PASSES + q + 1) * x_pass, ldS);
+            sg_stage<KT, SG_RING, true>(acc, x, lb + (SG_PASSES - 1) * PASS * KP, xrow, ldS);
+        }
 
-    if (active) {
-        float* out = slab + ((int64_t)sp * F + f0 + 4 * c) * KP + 4 * h;
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * SG_BLOCK_F + wave * SG_WAVE_F + 4 * c) * KP + 4 * h;
 #pragma unroll
         for (int m = 0; m < KT; ++m)
 #pragma unroll
@@ -175,9 +254,36 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = {acc[m][j][4 * q + 0], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
-                    // D row (k within tile m) = 8q + 4h + e, D column = lane&31 -> f = f0 + 4c + j
+                    // D row (k within tile m) = 8q + 4h + e, D column = lane&31 -> f_local = 128*wave + 4c + j
                     *reinterpret_cast<f32x4*>(out + (int64_t)j * KP + 32 * m + 8 * q) = v;
                 }
+    }
+    if (clk && tid == 0) {
+        clk[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
+        clk[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        clk[4 * blockIdx.x + 2] = clk_r0;                                       // start, 100 MHz ticks
+        clk[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
+    }
+}
+
+// out[f][k] = sum over the pieces of f's tile (ascending workgroup, float64 accumulation), f < rows
+__global__ __launch_bounds__(256)
+void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ out, int rows, int KP, SweepGeom g)
+{
+    const int kq = KP / 4;
+    const int64_t n4 = (int64_t)rows * kq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / kq), k4 = (int)(i % kq);
+        const int ft = f / SG_BLOCK_F, fl = f % SG_BLOCK_F;
+        int w_lo, w_hi;
+        sg_tile_pieces(g, ft, w_lo, w_hi);
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int w = w_lo; w <= w_hi; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl * KP + 4 * k4);
+            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+        }
+        f32x4 o = {(float)a0, (float)a1, (float)a2, (float)a3};
+        *reinterpret_cast<f32x4*>(out + (int64_t)f * KP + 4 * k4) = o;
     }
 }
 
@@ -460,7 +566,7 @@ void w_update_kernel(float* __restrict__ W, const float* __restrict__ XHt, const
 
 // ----------------------------------------------------------------------------------------------
 // h_update: rows of H (cells), one wave per 8 cells, lane = component k.
-//   num = guided_num + 2 * sum_s slabB[s][n][k]
+//   num = guided_num + 2 * sum over the W^TX pieces of n's tile
 //   den = guided_den + sum_k' (2 W^TW)[k'][k] * H[n][k']
 //   H[n][k] *= num / max(den, eps)                                              main.py:631-656
 // guided terms for the columns of covariate i (lanes off_i .. off_i+k_i-1, all within lanes 0..63):
@@ -468,7 +574,7 @@ void w_update_kernel(float* __restrict__ W, const float* __restrict__ XHt, const
 //   Fro: num = sum_c (2 lam B[c][k]) * Y[c][n],  den = sum_c (2 lam B[c][k]) * (B H_i)[c][n]          (:646-647)
 template <int KT>
 __global__ __launch_bounds__(256)
-void h_update_kernel(float* __restrict__ H, const float* __restrict__ slab, int nslab, int64_t slab_stride,
+void h_update_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
                      const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
                      CovMeta meta, int N, int64_t Np, int K, float eps, int nB)
 {
@@ -498,6 +604,10 @@ void h_update_kernel(float* __restrict__ H, const float* __restrict__ slab, int 
     const int gw = blockIdx.x * 4 + wave;
     const int64_t n0 = (int64_t)gw * UPD_ROWS;
     float hv[UPD_ROWS][NH], xv[UPD_ROWS][NH], den[UPD_ROWS][NH];
+    // the wave's 8 cells share one 512-cell tile of the W^TX sweep: sum that tile's pieces in ascending workgroup
+    const int ft = (int)(n0 / SG_BLOCK_F), fl0 = (int)(n0 % SG_BLOCK_F);
+    int w_lo, w_hi;
+    sg_tile_pieces(g, ft, w_lo, w_hi);
 #pragma unroll
     for (int i = 0; i < UPD_ROWS; ++i)
 #pragma unroll
@@ -506,7 +616,7 @@ void h_update_kernel(float* __restrict__ H, const float* __restrict__ slab, int 
             const bool ok = (n0 + i < N) && (k < KP);
             hv[i][hh] = ok ? H[(n0 + i) * KP + k] : 0.f;
             double a = 0.0;
-            if (ok) for (int s = 0; s < nslab; ++s) a += (double)slab[(int64_t)s * slab_stride + (n0 + i) * KP + k];
+            if (ok) for (int w = w_lo; w <= w_hi; ++w) a += (double)pieces[sg_piece_offset(g, w, ft, KP) + (int64_t)(fl0 + i) * KP + k];
             xv[i][hh] = (float)a;
             den[i][hh] = 0.f;
         }
