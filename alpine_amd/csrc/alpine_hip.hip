@@ -60,6 +60,7 @@ struct alpine_ctx {
     // timing-only ablation (env ALPINE_HIP_ABLATE_STRIDE0=1): the sweeps re-read row 0 of X (served from cache) -> wrong
     // results, prices the HBM stream against the MFMA pipeline.  Never set in tests or bench.
     bool ablate_stride0 = false;
+    bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     // profiling
     bool prof = false;
@@ -190,6 +191,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("ALPINE_HIP_ABLATE_STRIDE0")) c->ablate_stride0 = (e[0] == '1');
     if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
+    if (const char* e = std::getenv("ALPINE_HIP_H_UPDATE")) c->h_update_valu = (std::strcmp(e, "valu") == 0);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
 
@@ -607,10 +609,16 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
     if ((rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    const int hblocks = (int)((c->N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
     const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->piecesB, c->geomB,
-                                           c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
+    if (c->h_update_valu) {           // reference implementation of the same update on the VALU (A/B and fallback)
+        const int hblocks = (int)((c->N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->piecesB, c->geomB,
+                                               c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
+    } else {
+        const int hblocks = (int)((c->N + 127) / 128);
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->piecesB, c->geomB,
+                                               c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
+    }
     HIPCHK(c, hipGetLastError());
     c->pending_loss = true;
     return 0;

@@ -668,6 +668,136 @@ void h_update_kernel(float* __restrict__ H, const float* __restrict__ pieces, Sw
 }
 
 // ----------------------------------------------------------------------------------------------
+// h_update on MFMA: one wave = 32 cells, lane (c, h) = cell n0+c, k-half h.
+//   den[k][cell] = sum_k' (2 W^TW)[k][k'] * H[cell][k']  as  D = A*B  with  A[k][k'] = M2 (symmetric, read transposed
+//   from LDS: conflict-free), B[k'][cell] = H.  The contraction index is visited in the order
+//   k'(m,q,e; h) = 32m + 8q + 4h + e, which is exactly the set of k a lane owns in the MFMA C/D layout
+//   (row = 8q + 4h + e of tile m, column = cell): so a lane's float4 loads H[cell][32m+8q+4h .. +3] of the cell-major
+//   H rows ARE its B operands, and den lands element-for-element on the same registers' k.  No LDS round trip for H.
+// Guided terms (main.py:636-650) use the same registers: per covariate/class the lane forms its half of
+// (B_i H_i)[c'][cell] over the k it owns and adds the partner half (lane ^ 32).
+template <int KT>
+__global__ __launch_bounds__(256)
+void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
+                          const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
+                          CovMeta meta, int N, int64_t Np, int K, float eps, int nB)
+{
+    constexpr int KP = 32 * KT;
+    constexpr int GT = KT < 2 ? KT : 2;            // k tiles that can hold guided columns (sum k_i <= 64)
+    extern __shared__ float smem[];
+    float* M2l = smem;                             // [k'][k] = 2 * WtW
+    float* Bl = smem + KP * KP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    for (int idx = tid; idx < KP * KP; idx += 256) M2l[idx] = 2.f * WtW[idx];
+    for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];
+    __syncthreads();
+
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (n0 >= N) return;
+    const int64_t n = n0 + c;
+    const bool valid = n < N;
+    const int ft = (int)(n0 / SG_BLOCK_F), fl = (int)(n0 % SG_BLOCK_F) + c;
+    int w_lo, w_hi;
+    sg_tile_pieces(g, ft, w_lo, w_hi);
+
+    f32x4 hreg[KT][4], xreg[KT][4];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = 32 * m + 8 * q + 4 * h;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if (valid) {
+                hv = *reinterpret_cast<const f32x4*>(H + n * KP + k4);
+                for (int w = w_lo; w <= w_hi; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl * KP + k4);
+                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                }
+            }
+            hreg[m][q] = hv;
+            xreg[m][q] = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+        }
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int mo = 0; mo < KT; ++mo)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mo][e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* mrow = M2l + (32 * m + 8 * q + 4 * h + e) * KP + c;
+#pragma unroll
+                for (int mo = 0; mo < KT; ++mo)
+                    acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], hreg[m][q][e], acc[mo], 0, 0, 0);
+            }
+
+    // guided numerator / denominator for the k this lane owns in tiles 0..GT-1
+    f32x4 gnum[GT][4], gden[GT][4];
+#pragma unroll
+    for (int m = 0; m < GT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gnum[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; gden[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < meta.n_cov; ++i) {
+        const int off = meta.off[i], ki = meta.k[i], Ci = meta.lev[i], bo = meta.boff[i];
+        const float lam = (meta.loss_type == 0) ? meta.lam[i] : meta.lam2[i];
+        for (int cl = 0; cl < Ci; ++cl) {
+            const float* brow = Bl + bo + cl * ki - off;            // brow[k] = B_i[cl][k - off]
+            float part = 0.f;
+#pragma unroll
+            for (int m = 0; m < GT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 32 * m + 8 * q + 4 * h + e;
+                        const float coef = (k >= off && k < off + ki) ? brow[k] : 0.f;
+                        part = fmaf(coef, hreg[m][q][e], part);
+                    }
+            const float bh = part + __shfl_xor(part, 32, 64);
+            const float y = valid ? Y[(int64_t)(meta.yoff[i] + cl) * Np + n] : 0.f;
+            const float z = (meta.loss_type == 0) ? y / fmaxf(bh, eps) : y;
+#pragma unroll
+            for (int m = 0; m < GT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 32 * m + 8 * q + 4 * h + e;
+                        const float lb = (k >= off && k < off + ki) ? lam * brow[k] : 0.f;
+                        gnum[m][q][e] = fmaf(lb, z, gnum[m][q][e]);
+                        gden[m][q][e] = (meta.loss_type == 0) ? gden[m][q][e] + lb : fmaf(lb, bh, gden[m][q][e]);
+                    }
+        }
+    }
+
+    if (!valid) return;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = 32 * m + 8 * q + 4 * h;
+            if (k4 >= K) continue;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float num = 2.f * xreg[m][q][e];
+                float den = acc[m][4 * q + e];
+                if (m < GT) { num = gnum[m < GT ? m : 0][q][e] + num; den = gden[m < GT ? m : 0][q][e] + den; }
+                const float v = hreg[m][q][e] * (num / fmaxf(den, eps));
+                o[e] = (k4 + e < K) ? v : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(H + n * KP + k4) = o;
+        }
+}
+
+// ----------------------------------------------------------------------------------------------
 // b_update (one block): B_i <- B_i * num / max(den, eps), main.py:615-628, from the reduced statistics.
 __global__ __launch_bounds__(256)
 void b_update_kernel(const float* __restrict__ Bold, float* __restrict__ Bnew, const float* __restrict__ stats,
