@@ -232,7 +232,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     const int rows_per_gram_block = 4 * GR_ROWS_PER_WAVE;
     c->gramBlocksH = (int)((Np + rows_per_gram_block - 1) / rows_per_gram_block);
     c->gramBlocksW = (int)((Gp + rows_per_gram_block - 1) / rows_per_gram_block);
-    ALLOC(c, c->gramPart, float, (int64_t)std::max(c->gramBlocksH, c->gramBlocksW) * 4 * KP * KP);
+    ALLOC(c, c->gramPart, float, (int64_t)std::max(c->gramBlocksH, c->gramBlocksW) * KP * KP);
     c->statBlocks = (int)((c->N + HS_CELLS - 1) / HS_CELLS);
     ALLOC(c, c->statPart, float, (int64_t)c->statBlocks * std::max(1, c->nstat));
     ALLOC(c, c->kind, int, kind.size());
@@ -491,20 +491,14 @@ static int prof_end(alpine_ctx* c, int which)
     return 0;
 }
 
-static int launch_reduce(alpine_ctx* c, const float* in, float* out, int64_t n, int nslab)
-{
-    const int64_t n4 = n / 4;
-    const int blocks = (int)std::min<int64_t>(c->n_cu * 8, (n4 + 255) / 256);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(std::max(1, blocks)), dim3(256), 0, c->stream, in, out, n, nslab);
-    HIPCHK(c, hipGetLastError());
-    return 0;
-}
-
 static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int blocks, float* out)
 {
     DISPATCH_KT(c->KT, hipLaunchKernelGGL(gram_kernel<KT_>, dim3(blocks), dim3(256), 0, c->stream, A, c->gramPart, (int)R));
     HIPCHK(c, hipGetLastError());
-    return launch_reduce(c, c->gramPart, out, (int64_t)c->KP * c->KP, blocks * 4);
+    const int n = c->KP * c->KP;
+    hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, out, n, blocks);
+    HIPCHK(c, hipGetLastError());
+    return 0;
 }
 
 // the two streaming sweeps share one launcher; the variant only changes the pipeline shape, never the result

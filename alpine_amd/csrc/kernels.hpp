@@ -288,7 +288,7 @@ void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------
-// gram: part[w][k][k'] = sum_{r in rows of wave w} A[r][k] * A[r][k']     (A: R x KP, row-major)
+// gram: part[b][k][k'] = sum_{r in rows of block b} A[r][k] * A[r][k']     (A: R x KP, row-major)
 // Used for HH^T (A = H) and W^TW (A = W).  Each wave owns a contiguous row range; A and B MFMA
 // operands are the same registers.
 constexpr int GR_ROWS_PER_WAVE = 256;
@@ -326,31 +326,43 @@ void gram_kernel(const float* __restrict__ A, float* __restrict__ part, int R)
                 for (int b = 0; b < KT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][a], v[p][b], acc[a][b], 0, 0, 0);
     }
-    float* out = part + (int64_t)gw * KP * KP;
+    // the block's 4 waves are summed in wave order through LDS -> one partial per block (fixed order)
+    __shared__ float gl[KP * KP];
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
 #pragma unroll
-    for (int a = 0; a < KT; ++a)
+            for (int a = 0; a < KT; ++a)
 #pragma unroll
-        for (int b = 0; b < KT; ++b)
+                for (int b = 0; b < KT; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
-                out[row * KP + 32 * b + c] = acc[a][b][e];
-            }
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        float* q = &gl[row * KP + 32 * b + c];
+                        *q = (wv == 0 ? 0.f : *q) + acc[a][b][e];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = part + (int64_t)blockIdx.x * KP * KP;
+    for (int idx = threadIdx.x; idx < KP * KP; idx += 256) out[idx] = gl[idx];
 }
 
-// out[i] = sum_s in[s][i] (float64 accumulation, fixed order), i < n (n multiple of 4)
-__global__ __launch_bounds__(256)
-void reduce_slabs_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int nslab)
+// out[j] = sum_s in[s][j], small n, many slabs: block = 64 outputs x 16 slab groups; groups are combined in group
+// order (float64), so the sum order is fixed.
+__global__ __launch_bounds__(1024)
+void reduce_many_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int nslab)
 {
-    const int64_t n4 = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int s = 0; s < nslab; ++s) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(in + (int64_t)s * n + 4 * i);
-            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-        }
-        f32x4 o = {(float)a0, (float)a1, (float)a2, (float)a3};
-        *reinterpret_cast<f32x4*>(out + 4 * i) = o;
+    __shared__ double red[16][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    double a = 0.0;
+    if (j < n) for (int s = sg; s < nslab; s += 16) a += (double)in[(int64_t)s * n + j];
+    red[sg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (sg == 0 && j < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += red[u][threadIdx.x & 63];
+        out[j] = (float)t;
     }
 }
 
