@@ -16,13 +16,14 @@ LIB_PATH = os.path.join(_HERE, "libalpine_hip.so")
 LOSS_KL, LOSS_FROBENIUS = 0, 1
 X_CELLS_BY_GENES, X_GENES_BY_CELLS = 0, 1
 KERNEL_SWEEP_XHT, KERNEL_SWEEP_WTX = 0, 1
+FLAG_TRANSFORM_ONLY = 1
 BUF_REDUCE_BLOCK, BUF_WTW, BUF_W, BUF_H, BUF_X_GN, BUF_X_NG = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
     "alpine_reduce_block_floats", "alpine_create", "alpine_destroy", "alpine_last_error", "alpine_get_info",
     "alpine_upload_X_host", "alpine_upload_X_device", "alpine_finalize_X", "alpine_upload_Y",
     "alpine_set_factors", "alpine_get_factors", "alpine_iter_begin", "alpine_iter_end", "alpine_reduce_block",
-    "alpine_run", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
+    "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_get_kernel_time", "alpine_read_buffer",
 ]
 
@@ -86,6 +87,7 @@ def load() -> C.CDLL:
     lib.alpine_iter_end.argtypes = [p, i32]
     lib.alpine_reduce_block.argtypes = [p, C.POINTER(p), C.POINTER(i64)]
     lib.alpine_run.argtypes = [p, i32, i32]
+    lib.alpine_transform.argtypes = [p, i32]
     lib.alpine_get_losses.argtypes = [p, C.POINTER(C.c_double), i64, C.POINTER(i64)]
     lib.alpine_reset_losses.argtypes = [p]
     lib.alpine_scale.argtypes = [p]
@@ -112,7 +114,7 @@ class NativeShard:
                  cov_levels: Sequence[int], lam: Sequence[float], orth_W: float = 0.0, alpha_W: float = 0.0,
                  l1_ratio_W: float = 0.0, eps: float = 1e-6, loss_type: str = "kl-divergence",
                  device_id: int = 0, stream: Optional[int] = None, reduce_block: Optional[int] = None,
-                 split_a: int = 0, split_b: int = 0):
+                 split_a: int = 0, split_b: int = 0, transform_only: bool = False):
         self._lib = load()
         self._h = C.c_void_p()
         n_cov = len(cov_components)
@@ -127,7 +129,7 @@ class NativeShard:
         cfg.cov_components, cfg.cov_levels, cfg.lam = self._k, self._lev, self._lam
         cfg.orth_W, cfg.alpha_W, cfg.l1_ratio_W, cfg.eps = orth_W, alpha_W, l1_ratio_W, eps
         cfg.loss_type = LOSS_KL if loss_type == "kl-divergence" else LOSS_FROBENIUS
-        cfg.split_a, cfg.split_b, cfg.flags = split_a, split_b, 0
+        cfg.split_a, cfg.split_b, cfg.flags = split_a, split_b, (FLAG_TRANSFORM_ONLY if transform_only else 0)
         cfg.stream = stream
         cfg.reduce_block = reduce_block
         self._cfg = cfg
@@ -213,6 +215,9 @@ class NativeShard:
 
     def run(self, n_iters: int, with_loss: bool = True):
         self._chk(self._lib.alpine_run(self._h, n_iters, 1 if with_loss else 0))
+
+    def transform(self, n_iter: int):
+        self._chk(self._lib.alpine_transform(self._h, n_iter))
 
     def losses(self) -> np.ndarray:
         n = C.c_int64()

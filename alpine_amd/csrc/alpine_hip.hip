@@ -60,6 +60,7 @@ struct alpine_ctx {
     // timing-only ablation (env ALPINE_HIP_ABLATE_STRIDE0=1): the sweeps re-read row 0 of X (served from cache) -> wrong
     // results, prices the HBM stream against the MFMA pipeline.  Never set in tests or bench.
     bool ablate_stride0 = false;
+    bool transform_only = false;
     bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     // profiling
@@ -182,6 +183,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->nstat = g.nstat; c->nB = g.nB; c->nYrows = g.nYrows;
     c->orth = cfg->orth_W; c->alpha = cfg->alpha_W; c->l1r = cfg->l1_ratio_W; c->eps = cfg->eps;
     c->loss_type = cfg->loss_type;
+    c->transform_only = (cfg->flags & ALPINE_FLAG_TRANSFORM_ONLY) != 0;
     c->device = cfg->device_id;
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -217,13 +219,13 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->geomB = make_geom(Np, Gp, slots, cfg->split_b);       // W^TX: f = cells, r = genes
 
     ALLOC(c, c->Xgn, float, Gp * Np);
-    ALLOC(c, c->Xng, float, Np * Gp);
+    ALLOC(c, c->Xng, float, c->transform_only ? 4 : Np * Gp);
     ALLOC(c, c->W, float, Gp * KP);
     ALLOC(c, c->H, float, Np * KP);
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
     ALLOC(c, c->B[0], float, std::max(1, c->nB));
     ALLOC(c, c->B[1], float, std::max(1, c->nB));
-    ALLOC(c, c->piecesA, float, (int64_t)c->geomA.nwg * c->geomA.maxp * SG_BLOCK_F * KP);
+    ALLOC(c, c->piecesA, float, c->transform_only ? 4 : (int64_t)c->geomA.nwg * c->geomA.maxp * SG_BLOCK_F * KP);
     ALLOC(c, c->piecesB, float, (int64_t)c->geomB.nwg * c->geomB.maxp * SG_BLOCK_F * KP);
     c->red_floats = g.red_floats; c->red_hht = g.red_hht; c->red_stats = g.red_stats;
     if (cfg->reduce_block) { c->red = (float*)cfg->reduce_block; c->own_red = false; HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream)); }
@@ -301,15 +303,17 @@ static int upload_x_dev(alpine_ctx* c, const float* dev, int layout, int64_t ld,
 {
     const int G = c->G;
     if (layout == ALPINE_X_CELLS_BY_GENES) {
-        HIPCHK(c, hipMemcpy2DAsync(c->Xng + cell0 * c->Gp, sizeof(float) * c->Gp, dev, sizeof(float) * ld,
-                                   sizeof(float) * G, (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        if (!c->transform_only)
+            HIPCHK(c, hipMemcpy2DAsync(c->Xng + cell0 * c->Gp, sizeof(float) * c->Gp, dev, sizeof(float) * ld,
+                                       sizeof(float) * G, (size_t)n, hipMemcpyDeviceToDevice, c->stream));
         dim3 grid((G + 31) / 32, (unsigned)((n + 31) / 32));
         hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, dev, ld, c->Xgn + cell0, c->Np, (int)n, G);
     } else {
         HIPCHK(c, hipMemcpy2DAsync(c->Xgn + cell0, sizeof(float) * c->Np, dev, sizeof(float) * ld,
                                    sizeof(float) * (size_t)n, (size_t)G, hipMemcpyDeviceToDevice, c->stream));
         dim3 grid((unsigned)((n + 31) / 32), (G + 31) / 32);
-        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, dev, ld, c->Xng + cell0 * c->Gp, c->Gp, G, (int)n);
+        if (!c->transform_only)
+            hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, dev, ld, c->Xng + cell0 * c->Gp, c->Gp, G, (int)n);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -540,6 +544,7 @@ extern "C" int alpine_iter_begin(alpine_ctx* c)
 {
     int rc = ready(c);
     if (rc) return rc;
+    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
     const int KP = c->KP;
     if (c->n_cov > 0) {
         hipLaunchKernelGGL(hstats_kernel, dim3(c->statBlocks), dim3(HS_CELLS), 0, c->stream, c->H, c->Y, c->B[c->bcur], c->meta,
@@ -575,6 +580,7 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
 {
     int rc = ready(c);
     if (rc) return rc;
+    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
     const int KP = c->KP, K = c->K;
     const float l2 = (float)((1.0 - c->l1r) * c->alpha), l1 = (float)(c->l1r * c->alpha);
     const int wblocks = c->ndot / 4;
@@ -615,6 +621,24 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
     }
     HIPCHK(c, hipGetLastError());
     c->pending_loss = true;
+    return 0;
+}
+
+extern "C" int alpine_transform(alpine_ctx* c, int n_iter)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (n_iter < 0) return fail(c, ALPINE_ERR_BAD_ARG, "n_iter must be >= 0");
+    const int KP = c->KP;
+    if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
+    if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    if ((rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB))) return rc;
+    if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    const int hblocks = (int)((c->N + 127) / 128);
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_iterate_mfma_kernel<KT_>, dim3(hblocks), dim3(256), sizeof(float) * KP * KP, c->stream, c->H,
+                                           c->piecesB, c->geomB, c->WtW, c->N, c->K, (float)c->eps, n_iter));
+    HIPCHK(c, hipGetLastError());
+    c->pending_loss = false;
     return 0;
 }
 

@@ -810,6 +810,91 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
 }
 
 // ----------------------------------------------------------------------------------------------
+// transform (alpine/main.py:705-709): n_iter times  H *= (2 W^T X) / max((2 W^T W) H, eps)  with W frozen.
+// The numerator is loop-invariant (one W^TX sweep) and every cell is independent, so all iterations of a
+// 32-cell tile run in registers: the updated H in the MFMA C/D layout is directly the next iteration's B operand
+// (same k'(m,q,e;h) ordering as h_update_mfma_kernel).  One read of the pieces and H, one write of H.
+template <int KT>
+__global__ __launch_bounds__(256)
+void h_iterate_mfma_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
+                           const float* __restrict__ WtW, int N, int K, float eps, int n_iter)
+{
+    constexpr int KP = 32 * KT;
+    extern __shared__ float smem[];
+    float* M2l = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    for (int idx = tid; idx < KP * KP; idx += 256) M2l[idx] = 2.f * WtW[idx];
+    __syncthreads();
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (n0 >= N) return;
+    const int64_t n = n0 + c;
+    const bool valid = n < N;
+    const int ft = (int)(n0 / SG_BLOCK_F), fl = (int)(n0 % SG_BLOCK_F) + c;
+    int w_lo, w_hi;
+    sg_tile_pieces(g, ft, w_lo, w_hi);
+
+    f32x4 hreg[KT][4], num[KT][4];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = 32 * m + 8 * q + 4 * h;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if (valid) {
+                hv = *reinterpret_cast<const f32x4*>(H + n * KP + k4);
+                for (int w = w_lo; w <= w_hi; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl * KP + k4);
+                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                }
+            }
+            hreg[m][q] = hv;
+            num[m][q] = f32x4{2.f * (float)a0, 2.f * (float)a1, 2.f * (float)a2, 2.f * (float)a3};
+        }
+
+    for (int it = 0; it < n_iter; ++it) {
+        f32x16 acc[KT];
+#pragma unroll
+        for (int mo = 0; mo < KT; ++mo)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mo][e] = 0.f;
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* mrow = M2l + (32 * m + 8 * q + 4 * h + e) * KP + c;
+#pragma unroll
+                    for (int mo = 0; mo < KT; ++mo)
+                        acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], hreg[m][q][e], acc[mo], 0, 0, 0);
+                }
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    hreg[m][q][e] = hreg[m][q][e] * (num[m][q][e] / fmaxf(acc[m][4 * q + e], eps));
+    }
+
+    if (!valid) return;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = 32 * m + 8 * q + 4 * h;
+            if (k4 >= K) continue;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (k4 + e < K) ? hreg[m][q][e] : 0.f;
+            *reinterpret_cast<f32x4*>(H + n * KP + k4) = o;
+        }
+}
+
+// ----------------------------------------------------------------------------------------------
 // b_update (one block): B_i <- B_i * num / max(den, eps), main.py:615-628, from the reduced statistics.
 __global__ __launch_bounds__(256)
 void b_update_kernel(const float* __restrict__ Bold, float* __restrict__ Bnew, const float* __restrict__ stats,

@@ -11,7 +11,7 @@ class: ``device="cpu"`` raises.
 from __future__ import annotations
 
 import math
-from copy import copy
+from copy import copy, deepcopy
 from typing import Dict, List, Optional, Union
 
 import numpy as np
@@ -161,6 +161,11 @@ class ALPINE:
         n_loc = c1 - c0
         cov_levels = [y.shape[1] for y in Y]
         W0, H0, B0 = draw_initial_factors(self.random_state, self.eps, G, N_total, self.n_all_components, cov_levels)
+        # The reference's loop also draws torch.randperm(N) once per iteration from the global generator
+        # (sampling.py:14).  Full batch makes the permutation a numerical no-op, so it is not applied, but a later
+        # unseeded transform() (main.py:687) continues that stream: remember how to advance it lazily.
+        self._rng_post_init = torch.get_rng_state()
+        self._rng_replay = (N_total, n_iter)
 
         kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
@@ -204,6 +209,68 @@ class ALPINE:
             H = H_loc
         colnames = ["total loss", "reconstruction loss"] + [f"prediction loss({k})" for k in self.covariate_keys]
         return dict(W=W, H=H, Bs=Bs, loss_history=pd.DataFrame(losses, columns=colnames), info=info_d)
+
+    # ------------------------------------------------------ transform (main.py:149-185, :678-724)
+    def transform(self, adata, n_iter: Optional[int] = None) -> None:
+        if not hasattr(self, "matrices"):
+            raise RuntimeError("Model is not trained yet. Please fit the model first.")
+        if not is_anndata(adata):
+            raise TypeError("adata must be an AnnData object.")
+        if not isinstance(n_iter, (int, type(None))) or (n_iter is not None and n_iter <= 0):
+            raise ValueError("n_iter must be a positive integer or None.")
+        n_iter = n_iter if n_iter is not None else self.max_iter
+        self._transform(adata, n_iter)
+
+    def fit_transform(self, adata, covariate_keys: List[str], batch_size: Optional[int] = None,
+                      max_iter: Optional[int] = None, sampling_method: str = "random", verbose: bool = False) -> None:
+        self.fit(adata, covariate_keys, batch_size=batch_size, max_iter=max_iter, sampling_method=sampling_method,
+                 verbose=verbose).transform(adata)
+
+    def _advance_rng_like_reference_fit(self) -> None:
+        """Bring the global torch generator to where the reference's fit() would have left it (init draws, then
+        one randperm(N) per iteration), provided nobody else has drawn from it since our init draws."""
+        replay = getattr(self, "_rng_replay", None)
+        if replay is None:
+            return
+        self._rng_replay = None
+        if torch.equal(torch.get_rng_state(), self._rng_post_init):
+            n_total, n_iter = replay
+            for _ in range(n_iter):
+                torch.randperm(n_total)
+
+    def _transform(self, adata, n_iter: int) -> None:
+        X = adata.X
+        if not np.all(X >= 0):
+            raise ValueError("All elements in adata.X must be non-negative.")
+        n_sample, G = X.shape
+        dev_index = _parse_device(str(self.device))
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: alpine_amd needs an MI355X (there is no CPU fallback)")
+        if dev_index < 0:
+            dev_index = torch.cuda.current_device()
+        self._advance_rng_like_reference_fit()
+        # main.py:687-689: U[0,1) from the global generator, NOT reseeded, NOT clamped
+        H0 = torch.rand((self.total_components, n_sample), dtype=torch.float32).numpy()
+        W = np.ascontiguousarray(np.concatenate(self.matrices["Ws"], axis=1), dtype=np.float32)
+        eng = _native.NativeShard(n_genes=G, n_cells=n_sample, n_components=self.total_components, cov_components=[],
+                                  cov_levels=[], lam=[], eps=self.eps, device_id=dev_index, transform_only=True)
+        try:
+            chunk = max(1, (1 << 28) // (4 * G))
+            for r0 in range(0, n_sample, chunk):
+                eng.upload_X_host(np.ascontiguousarray(X[r0:r0 + chunk], dtype=np.float32), _native.X_CELLS_BY_GENES, r0)
+            eng.finalize_X()
+            eng.set_factors(W, H0, [])
+            eng.transform(n_iter)
+            _, H, _ = eng.get_factors()
+        finally:
+            eng.close()
+        offs = np.cumsum([0] + self.n_all_components)
+        Hs = [H[offs[j]:offs[j + 1]] for j in range(len(self.n_all_components))]
+        for i, covariate in enumerate(self.covariate_keys):
+            adata.obsm[covariate] = np.ascontiguousarray(Hs[i].T)
+            adata.varm[covariate] = deepcopy(self.matrices["Ws"][i])
+        adata.obsm["ALPINE_embedding"] = np.ascontiguousarray(Hs[-1].T)
+        adata.varm["ALPINE_weights"] = deepcopy(self.matrices["Ws"][-1])
 
     # ------------------------------------------------- store_embeddings (main.py:303-320)
     def store_embeddings(self, adata) -> None:

@@ -42,6 +42,9 @@ typedef enum {
 } alpine_status;
 
 enum { ALPINE_LOSS_KL = 0, ALPINE_LOSS_FROBENIUS = 1 };      /* main.py:57, :371 */
+/* alpine_config.flags: a ctx that will only run alpine_transform keeps a single copy of X (genes x cells) and no
+ * resources of the XH^T sweep; alpine_iter_begin / alpine_run then fail with ALPINE_ERR_STATE. */
+enum { ALPINE_FLAG_TRANSFORM_ONLY = 1 };
 enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
 
 /* Constructor arguments of ALPINE (main.py:47-61) plus the shard geometry. */
@@ -60,9 +63,9 @@ typedef struct {
     double l1_ratio_W;              /* main.py:54 */
     double eps;                     /* main.py:59 */
     int32_t loss_type;              /* ALPINE_LOSS_*           (main.py:57) */
-    int32_t split_a;                /* #partial slabs of the XH^T sweep, 0 = choose */
-    int32_t split_b;                /* #partial slabs of the W^TX sweep, 0 = choose */
-    int32_t flags;                  /* reserved, 0 */
+    int32_t split_a;                /* XH^T sweep: ~partial pieces per 512-wide tile; 0 = one equal span per resident workgroup */
+    int32_t split_b;                /* W^TX sweep: same */
+    int32_t flags;                  /* ALPINE_FLAG_* */
     void* stream;                   /* hipStream_t to enqueue on, NULL = the library creates one */
     void* reduce_block;             /* optional device buffer of alpine_reduce_block_floats() floats that the
                                        caller owns (e.g. a torch tensor it will all-reduce); NULL = library allocates */
@@ -72,7 +75,7 @@ typedef struct {
     int32_t abi_version;
     int32_t k_total;                /* K = sum(k_i) + K_u */
     int32_t k_padded;               /* KP: K rounded up to a multiple of 32 (one MFMA tile) */
-    int32_t split_a, split_b;       /* slabs actually used */
+    int32_t split_a, split_b;       /* partial pieces a workgroup may write (stream-K spans can cross tiles) */
     int32_t grid_a, grid_b;         /* workgroups of the two sweeps */
     int64_t genes_padded, cells_padded;   /* leading dimensions of the two resident copies of X */
     int64_t reduce_block_floats;
@@ -127,6 +130,11 @@ int alpine_run(alpine_ctx* ctx, int n_iters, int with_loss);
 /* Loss rows accumulated so far (float64, n_rows x (C+2)); synchronises the stream. */
 int alpine_get_losses(alpine_ctx* ctx, double* rows, int64_t max_rows, int64_t* n_rows);
 int alpine_reset_losses(alpine_ctx* ctx);
+
+/* Replaces the loop of ALPINE._transform (alpine/main.py:705-709): n_iter times H *= 2W^TX / max(2W^T(WH), eps) with W
+ * frozen and no covariate terms, from the W and H given to alpine_set_factors (B is ignored; pass NULL with
+ * n_covariates = 0).  One W^TX sweep, then all iterations of a cell tile in registers.  Asynchronous. */
+int alpine_transform(alpine_ctx* ctx, int n_iter);
 
 /* Replaces ALPINE._scale_matrices (main.py:772-781). */
 int alpine_scale(alpine_ctx* ctx);

@@ -15,6 +15,7 @@ It restates, in torch-CPU float32 (the arithmetic the reference itself uses on
                            alpine/utils/sampling.py:6-16, :58-71)
 * ``loss_row``          <- ``ALPINE._compute_loss``           alpine/main.py:726-753
 * ``scale_factors``     <- ``ALPINE._scale_matrices``         alpine/main.py:772-781
+* ``transform_faithful``<- loop of ``ALPINE._transform``      alpine/main.py:705-709
 * ``fit_faithful``      <- the loop ``ALPINE._fit``           alpine/main.py:486-676
 * ``mu_step_fused`` / ``fit_fused``: the SAME mathematics re-associated the way the HIP
   kernels evaluate it (``W(HH^T)``, ``(W^TW)H``, identity cell order, trace-form loss);
@@ -299,6 +300,20 @@ def scale_factors(p: OracleParams, s: OracleState) -> None:
         if j < len(p.n_covariate_components):
             s.Bs[j] = s.Bs[j] / sc
     s.W, s.H = Wn, Hn
+
+
+# ----------------------------------------------------------------------- transform
+def transform_faithful(eps: float, W: torch.Tensor, X_gn: torch.Tensor, H0: torch.Tensor, n_iter: int) -> torch.Tensor:
+    """main.py:705-709: ``H *= 2 W^T X / clamp(2 W^T (W H), eps)`` n_iter times with W frozen (H0 is the unclamped,
+    unseeded ``torch.rand`` draw of main.py:687-689; the caller provides it so the RNG stream can be mirrored)."""
+    H = H0.clone()
+    with torch.no_grad():
+        for _ in range(n_iter):
+            num = 2 * W.T @ X_gn
+            den = 2 * W.T @ (W @ H)
+            den = torch.clamp(den, min=eps)
+            H *= num / den
+    return H
 
 
 # ---------------------------------------------------------------- common evaluator

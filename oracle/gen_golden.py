@@ -83,7 +83,7 @@ def make_case_inputs(case: dict):
 
 
 CASES = [
-    dict(name="kl_1cov", n_cells=96, n_genes=64, seed=0, T=50,
+    dict(name="kl_1cov", transform_iters=15, n_cells=96, n_genes=64, seed=0, T=50,
          covariates=[("cond", ["a", "b"], 0.0)],
          params=dict(n_components=4, n_covariate_components=[2], lam=[1e3])),
     dict(name="fro_1cov", n_cells=96, n_genes=64, seed=1, T=50,
@@ -93,20 +93,20 @@ CASES = [
          covariates=[("cond", ["ctl", "stim"], 0.0)],
          params=dict(n_components=4, n_covariate_components=[2], lam=[1e3],
                      orth_W=0.1, alpha_W=0.5, l1_ratio_W=0.3)),
-    dict(name="kl_2cov_nan", n_cells=120, n_genes=80, seed=3, T=30,
+    dict(name="kl_2cov_nan", transform_iters=15, n_cells=120, n_genes=80, seed=3, T=30,
          covariates=[("c1", ["x", "y", "z"], 0.1), ("c2", ["p", "q"], 0.05)],
          params=dict(n_components=5, n_covariate_components=[2, 3], lam=[1e3, 5e2])),
     dict(name="fro_2cov_reg", n_cells=120, n_genes=80, seed=4, T=30,
          covariates=[("c1", ["x", "y", "z"], 0.1), ("c2", ["p", "q"], 0.0)],
          params=dict(n_components=5, n_covariate_components=[2, 3], lam=[5.0, 2.0],
                      loss_type="frobenius", orth_W=0.05, alpha_W=0.2, l1_ratio_W=0.5)),
-    dict(name="ragged", n_cells=257, n_genes=130, seed=5, T=20,
+    dict(name="ragged", transform_iters=15, n_cells=257, n_genes=130, seed=5, T=20,
          covariates=[("cond", ["a", "b"], 0.0)],
          params=dict(n_components=7, n_covariate_components=[3], lam=[1e3])),
     dict(name="one_iter", n_cells=96, n_genes=64, seed=6, T=1,
          covariates=[("cond", ["a", "b"], 0.0)],
          params=dict(n_components=4, n_covariate_components=[2], lam=[1e3])),
-    dict(name="k74", n_cells=300, n_genes=150, seed=7, T=10,
+    dict(name="k74", transform_iters=15, n_cells=300, n_genes=150, seed=7, T=10,
          covariates=[("cond", ["a", "b", "c"], 0.0)],
          params=dict(n_components=70, n_covariate_components=[4], lam=[1e3])),
     dict(name="k105", n_cells=200, n_genes=160, seed=8, T=5,
@@ -167,12 +167,20 @@ def run_case(case: dict, AnnData, out_dir: str):
         out[f"BT_{i}"] = b
     for i, y in enumerate(ms.matrices["Ys"]):
         out[f"Y_{i}"] = y                                   # C_i x N as the reference holds it
+    # transform (main.py:149-167, :678-724) right after fit, on a different set of cells (the first 2/3), so the
+    # unseeded torch.rand init continues the fit's RNG stream exactly as a user would see it
+    if case.get("transform_iters"):
+        n_t = (2 * case["n_cells"]) // 3
+        a_t = AnnData(X[:n_t].copy(), obs.iloc[:n_t].copy())
+        ms.transform(a_t, n_iter=case["transform_iters"])
+        Ht = [np.asarray(a_t.obsm[k]).T for k in keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T]
+        out["H_transform"] = np.concatenate(Ht, axis=0).astype(np.float32)
     out["loss_history"] = ms.loss_history.to_numpy(dtype=np.float64)
     assert np.array_equal(mu.loss_history.to_numpy(), ms.loss_history.to_numpy())
 
     meta = dict(
         name=case["name"], n_cells=case["n_cells"], n_genes=case["n_genes"], seed=case["seed"],
-        T=case["T"], data=case.get("data", "gamma"), covariate_keys=keys,
+        T=case["T"], data=case.get("data", "gamma"), covariate_keys=keys, transform_iters=case.get("transform_iters", 0),
         covariates=[[k, lv, nf] for k, lv, nf in case["covariates"]],
         params=params, loss_columns=list(ms.loss_history.columns),
         encoded_labels=ms.fe.encoded_labels,

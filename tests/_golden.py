@@ -51,6 +51,8 @@ def load_case(name: str) -> SimpleNamespace:
         setattr(c, f"H{tag}", z[f"H{tag}"])
         setattr(c, f"B{tag}", [z[f"B{tag}_{i}"] for i in range(n_cov)])
     c.Ys = [z[f"Y_{i}"] for i in range(n_cov)]          # C_i x N
+    c.transform_iters = meta.get("transform_iters", 0)
+    c.H_transform = z["H_transform"] if "H_transform" in z.files else None
     return c
 
 

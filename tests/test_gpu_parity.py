@@ -270,3 +270,60 @@ def test_errors_are_loud():
     eng.close()
     with pytest.raises(nat.AlpineNativeError):
         nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0])
+
+
+TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74"]
+
+
+@pytest.mark.parametrize("name", TRANSFORM_CASES)
+def test_transform_kernel_vs_oracle(name):
+    """alpine_transform (one W^TX sweep + in-register iterations) against the oracle's op-for-op loop, same H0."""
+    from oracle import alpine_oracle as orc
+    nat = _native()
+    c = load_case(name)
+    K = c.WT.shape[1]
+    n_t = (2 * c.X.shape[0]) // 3
+    rng = np.random.default_rng(5)
+    H0 = rng.random((K, n_t), dtype=np.float32)
+    Xt = np.ascontiguousarray(c.X[:n_t])
+    eng = nat.NativeShard(n_genes=c.X.shape[1], n_cells=n_t, n_components=K, cov_components=[], cov_levels=[], lam=[],
+                          transform_only=True)
+    eng.upload_X_host(Xt)
+    eng.finalize_X()
+    eng.set_factors(c.WT, H0, [])
+    eng.transform(c.transform_iters)
+    _, H, _ = eng.get_factors()
+    with pytest.raises(nat.AlpineNativeError):
+        eng.run(1)                                     # a transform-only ctx refuses the fit loop, loudly
+    eng.close()
+    want = orc.transform_faithful(1e-6, torch.tensor(c.WT), torch.tensor(np.ascontiguousarray(Xt.T)), torch.tensor(H0),
+                                  c.transform_iters).numpy()
+    assert rel_fro(H, want) < 2e-5
+    assert (H >= 0).all() and np.isfinite(H).all()
+
+
+@pytest.mark.parametrize("name", TRANSFORM_CASES)
+def test_fit_then_transform_drop_in(name):
+    """ALPINE.fit(...).transform(adata_t, n_iter) through the Python boundary vs the reference's own output
+    (same RNG stream, so the unseeded init of transform is identical)."""
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case(name)
+    adata = MiniAnnData(c.X.copy(), c.obs.copy())
+    model = ALPINE(device="cuda", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
+    n_t = (2 * c.X.shape[0]) // 3
+    a_t = MiniAnnData(c.X[:n_t].copy(), c.obs.iloc[:n_t].copy())
+    model.transform(a_t, n_iter=c.transform_iters)
+    Ht = np.concatenate([a_t.obsm[k].T for k in c.keys] + [a_t.obsm["ALPINE_embedding"].T], axis=0)
+    assert Ht.shape == c.H_transform.shape and Ht.dtype == np.float32
+    assert rel_fro(Ht, c.H_transform) < 1e-4
+    assert set(a_t.varm) == set(c.keys) | {"ALPINE_weights"}
+    assert np.array_equal(a_t.varm["ALPINE_weights"], model.matrices["Ws"][-1])
+    with pytest.raises(ValueError, match="n_iter must be a positive integer or None."):
+        model.transform(a_t, n_iter=0)
+
+
+def test_transform_before_fit_raises():
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case("kl_1cov")
+    with pytest.raises(RuntimeError, match="Model is not trained yet"):
+        ALPINE(device="cuda", **c.params).transform(MiniAnnData(c.X, c.obs))

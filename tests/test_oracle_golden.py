@@ -95,3 +95,19 @@ def test_common_evaluator_matches_direct_loss():
     c = load_case("kl_1cov")
     got = orc.recon_loss_f64(np.ascontiguousarray(c.X.T), c.WT_unscaled, c.HT_unscaled)
     assert abs(got - c.loss_history[-1, 1]) / c.loss_history[-1, 1] < 1e-5
+
+
+@pytest.mark.parametrize("name", [n for n in SMALL_CASES if load_case(n).H_transform is not None])
+def test_transform_oracle_reproduces_reference(name):
+    """fit (same RNG stream: init draws + one randperm per iteration), scale, then the unseeded torch.rand init
+    of transform on the first 2/3 of the cells -- must land on the reference's transform output."""
+    c = load_case(name)
+    p = _params(c)
+    s = _state(c, p)
+    orc.fit_faithful(p, s, c.T, use_perm=True, with_loss=False)
+    orc.scale_factors(p, s)
+    n_t = (2 * c.X.shape[0]) // 3
+    H0 = torch.rand((p.total_components, n_t), dtype=torch.float32)
+    Ht = orc.transform_faithful(p.eps, s.W, torch.tensor(np.ascontiguousarray(c.X[:n_t].T)), H0, c.transform_iters)
+    assert Ht.shape == c.H_transform.shape
+    assert rel_fro(Ht.numpy(), c.H_transform) < 5e-5
