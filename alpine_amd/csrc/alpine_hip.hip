@@ -2,6 +2,7 @@
 // Host side of one shard (one GPU) of ALPINE's full-batch MU fit loop (alpine/main.py:486-676).
 #include "../../include/alpine_hip.h"
 #include "kernels.hpp"
+#include "kernels_bf16.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -33,6 +34,8 @@ struct alpine_ctx {
     // device buffers
     float *Xgn = nullptr, *Xng = nullptr, *W = nullptr, *H = nullptr, *Y = nullptr, *B[2] = {nullptr, nullptr};
     int bcur = 0;
+    unsigned short *Xgn16 = nullptr, *Xng16 = nullptr, *Wp16 = nullptr, *Hp16 = nullptr;   // bf16 path (k-packed)
+    bool bf16 = false;
     float *piecesA = nullptr, *piecesB = nullptr;     // stream-K partial results of the two sweeps
     SweepGeom geomA{}, geomB{};
     float* red = nullptr;
@@ -184,6 +187,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->orth = cfg->orth_W; c->alpha = cfg->alpha_W; c->l1r = cfg->l1_ratio_W; c->eps = cfg->eps;
     c->loss_type = cfg->loss_type;
     c->transform_only = (cfg->flags & ALPINE_FLAG_TRANSFORM_ONLY) != 0;
+    c->bf16 = (cfg->flags & ALPINE_FLAG_X_BF16) != 0;
     c->device = cfg->device_id;
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -218,8 +222,14 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->geomA = make_geom(Gp, Np, slots, cfg->split_a);       // XH^T: f = genes, r = cells
     c->geomB = make_geom(Np, Gp, slots, cfg->split_b);       // W^TX: f = cells, r = genes
 
-    ALLOC(c, c->Xgn, float, Gp * Np);
-    ALLOC(c, c->Xng, float, c->transform_only ? 4 : Np * Gp);
+    ALLOC(c, c->Xgn, float, c->bf16 ? 4 : Gp * Np);
+    ALLOC(c, c->Xng, float, (c->transform_only || c->bf16) ? 4 : Np * Gp);
+    if (c->bf16) {
+        ALLOC(c, c->Xgn16, unsigned short, Gp * Np);
+        ALLOC(c, c->Xng16, unsigned short, c->transform_only ? 8 : Np * Gp);
+        ALLOC(c, c->Wp16, unsigned short, Gp * KP);
+        ALLOC(c, c->Hp16, unsigned short, Np * KP);
+    }
     ALLOC(c, c->W, float, Gp * KP);
     ALLOC(c, c->H, float, Np * KP);
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
@@ -275,7 +285,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtW, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtW, c->Xgn16, c->Xng16, c->Wp16, c->Hp16, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -299,9 +309,30 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
 }
 
 // ---------------------------------------------------------------------------------- ingest
+static int launch_pack(alpine_ctx* c, const float* src, int64_t ld, int rows, int cols, unsigned short* dst, int64_t dst_cols,
+                       int64_t k0, int64_t f0, int rows_are_k)
+{
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, c->stream, src, ld, rows, cols, dst, dst_cols, k0, f0, rows_are_k);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 static int upload_x_dev(alpine_ctx* c, const float* dev, int layout, int64_t ld, int64_t cell0, int64_t n)
 {
     const int G = c->G;
+    if (c->bf16) {
+        if (cell0 % 8) return fail(c, ALPINE_ERR_BAD_ARG, "bf16 path: X chunks must start at a multiple of 8 cells (got %lld)", (long long)cell0);
+        int rc;
+        if (layout == ALPINE_X_CELLS_BY_GENES) {            // chunk[cell][gene]
+            if (!c->transform_only && (rc = launch_pack(c, dev, ld, (int)n, G, c->Xng16, c->Gp, cell0, 0, 1))) return rc;   // k = cell
+            if ((rc = launch_pack(c, dev, ld, (int)n, G, c->Xgn16, c->Np, 0, cell0, 0))) return rc;                          // k = gene
+        } else {                                            // chunk[gene][cell]
+            if ((rc = launch_pack(c, dev, ld, G, (int)n, c->Xgn16, c->Np, 0, cell0, 1))) return rc;                          // k = gene
+            if (!c->transform_only && (rc = launch_pack(c, dev, ld, G, (int)n, c->Xng16, c->Gp, cell0, 0, 0))) return rc;   // k = cell
+        }
+        return 0;
+    }
     if (layout == ALPINE_X_CELLS_BY_GENES) {
         if (!c->transform_only)
             HIPCHK(c, hipMemcpy2DAsync(c->Xng + cell0 * c->Gp, sizeof(float) * c->Gp, dev, sizeof(float) * ld,
@@ -389,9 +420,10 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
     if (!c) return ALPINE_ERR_BAD_ARG;
     if (c->x_cells_uploaded < c->N) return fail(c, ALPINE_ERR_STATE, "only %lld of %d cells of X were uploaded", (long long)c->x_cells_uploaded, c->N);
     HIPCHK(c, hipSetDevice(c->device));
-    const int64_t n4 = c->Gp * c->Np / 4;
+    const int64_t n4 = c->Gp * c->Np / (c->bf16 ? 8 : 4);
     const int blocks = (int)std::min<int64_t>(4096, (n4 + 255) / 256);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn, n4, c->f64part);
+    if (c->bf16) hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn16, n4, c->f64part);
+    else hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn, n4, c->f64part);
     HIPCHK(c, hipGetLastError());
     int rc = sum_f64_partials(c, blocks, &c->xnorm2);
     if (rc) return rc;
@@ -506,8 +538,24 @@ static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int blocks, flo
 }
 
 // the two streaming sweeps share one launcher; the variant only changes the pipeline shape, never the result
+// which: 0 = XH^T (S = cells x genes copy, panel H), 1 = W^TX (S = genes x cells copy, panel W)
+static int launch_sweep_bf16(alpine_ctx* c, int which)
+{
+    const SweepGeom& g = which == 0 ? c->geomA : c->geomB;
+    const float* master = which == 0 ? c->H : c->W;
+    unsigned short* panel = which == 0 ? c->Hp16 : c->Wp16;
+    int rc = launch_pack(c, master, c->KP, g.R, c->KP, panel, c->KP, 0, 0, 1);      // float32 master -> k-packed bf16 operand copy
+    if (rc) return rc;
+    const unsigned short* S = which == 0 ? c->Xng16 : c->Xgn16;
+    float* pieces = which == 0 ? c->piecesA : c->piecesB;
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(stream_gemm_bf16_kernel<KT_>, dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, panel, pieces, g));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces)
 {
+    if (c->bf16) return launch_sweep_bf16(c, &g == &c->geomA ? 0 : 1);
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
 #define SG_LAUNCH(RING, PASSES) \
     DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_kernel<KT_, RING, PASSES>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, P, pieces, ldS, g, (unsigned long long*)nullptr))
@@ -717,6 +765,7 @@ extern "C" int alpine_eval_recon_direct(alpine_ctx* c, double* out)
 {
     int rc = ready(c);
     if (rc) return rc;
+    if (c->bf16 || c->transform_only) return fail(c, ALPINE_ERR_UNSUPPORTED, "direct evaluation needs the float32 cells x genes copy of X");
     if (!out) return fail(c, ALPINE_ERR_BAD_ARG, "out is NULL");
     const int gx = (c->G + 255) / 256;
     int cells_per_block = 256;
@@ -761,8 +810,8 @@ extern "C" int alpine_read_buffer(alpine_ctx* c, int which, int64_t offset, int6
         case ALPINE_BUF_WTW: base = c->WtW; size = (int64_t)c->KP * c->KP; break;
         case ALPINE_BUF_W: base = c->W; size = c->Gp * c->KP; break;
         case ALPINE_BUF_H: base = c->H; size = c->Np * c->KP; break;
-        case ALPINE_BUF_X_GENES_BY_CELLS: base = c->Xgn; size = c->Gp * c->Np; break;
-        case ALPINE_BUF_X_CELLS_BY_GENES: base = c->Xng; size = c->Np * c->Gp; break;
+        case ALPINE_BUF_X_GENES_BY_CELLS: base = c->Xgn; size = c->bf16 ? 0 : c->Gp * c->Np; break;
+        case ALPINE_BUF_X_CELLS_BY_GENES: base = c->Xng; size = (c->bf16 || c->transform_only) ? 0 : c->Np * c->Gp; break;
         default: return fail(c, ALPINE_ERR_BAD_ARG, "unknown buffer %d", which);
     }
     if (offset + n > size) return fail(c, ALPINE_ERR_BAD_ARG, "range outside buffer (%lld floats)", (long long)size);

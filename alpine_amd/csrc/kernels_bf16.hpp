@@ -1,0 +1,241 @@
+// bf16-storage path of the two streaming sweeps (BASELINE config 5): X and the MFMA operand copies of W / H are
+// bf16, accumulation and every update stay float32 (master W, H, B are float32; kernels.hpp).
+//
+// Layout ("k-packed"): a matrix whose ROW index r is the contraction index is stored as
+//     packed[r / 8][col][r % 8]            (bf16; 8 consecutive rows of one column are 16 contiguous bytes)
+// v_mfma_f32_32x32x16_bf16 takes, per lane (i = lane & 31, hh = lane >> 5), the 8 values A[i][8hh..8hh+7] and
+// B[8hh..8hh+7][i].  With the k-packed layout BOTH fragments are one aligned 16-byte load:
+//     B (streamed X):   packedS[(r0/8 + hh)][f0 + i][0..7]   -- 32 lanes x 16 B = 512 contiguous bytes per half-wave,
+//                       straight from HBM into the MFMA operand registers: no LDS, no transposes, no shuffles
+//     A (panel W or H): packedP[(r0/8 + hh)][32m + i][0..7]  -- staged through LDS as a plain contiguous copy
+// X is static, so the packing is paid once at ingest (pack_bf16_kernel); the panels are re-packed from the float32
+// masters once per sweep (KP columns only, ~1 % of the traffic of the sweep).
+// Arithmetic intensity is K flop/B, the bf16 MFMA rate is 16x the fp32 one: this path is HBM-bound by a wide margin.
+#pragma once
+#include "kernels.hpp"
+#include <hip/hip_bf16.h>
+
+namespace alpine {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float x)
+{
+    return __builtin_bit_cast(unsigned short, __float2bfloat16(x));     // round to nearest even, NaN stays NaN
+}
+
+// dst k-packed from a float32 row-major source tile: dst[(k / 8)][f][k % 8] = src[r][c] with
+//   rows_are_k != 0:  k = k0 + r, f = f0 + c          rows_are_k == 0:  k = k0 + c, f = f0 + r        (k0 % 8 == 0)
+// dst has `dst_cols` f-columns.  Block = 64 x 64 source tile through LDS; every 16-byte destination granule is
+// written whole by one thread (granules whose 8 k's are not all inside the source get zeros for the missing ones).
+__global__ __launch_bounds__(256)
+void pack_bf16_kernel(const float* __restrict__ src, int64_t ld_src, int rows, int cols, unsigned short* __restrict__ dst,
+                      int64_t dst_cols, int64_t k0, int64_t f0, int rows_are_k)
+{
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    for (int i = t; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(int64_t)(r0 + r) * ld_src + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = t; i < 512; i += 256) {
+        const int kb = i >> 6, fi = i & 63;                      // 8 k-blocks x 64 f positions of this tile
+        unsigned short v[8];
+        int64_t k_abs, f_abs;
+        if (rows_are_k) {
+            if (c0 + fi >= cols || r0 + 8 * kb >= rows) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f32_to_bf16_bits(tile[8 * kb + j][fi]);
+            k_abs = k0 + r0 + 8 * kb; f_abs = f0 + c0 + fi;
+        } else {
+            if (r0 + fi >= rows || c0 + 8 * kb >= cols) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f32_to_bf16_bits(tile[fi][8 * kb + j]);
+            k_abs = k0 + c0 + 8 * kb; f_abs = f0 + r0 + fi;
+        }
+        u32x4 o = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                   (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+        *reinterpret_cast<u32x4*>(dst + ((k_abs / 8) * dst_cols + f_abs) * 8) = o;
+    }
+}
+
+// sum of squares of a k-packed bf16 array (n8 granules of 8) in float64
+__global__ __launch_bounds__(256)
+void sqnorm_bf16_kernel(const unsigned short* __restrict__ x, int64_t n8, double* __restrict__ part)
+{
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+            a += (double)lo * lo + (double)hi * hi;
+        }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// ----------------------------------------------------------------------------------------------
+// stream_gemm, bf16 operands: out[f][k] = sum_r S[r][f] * P[r][k], same stream-K work division, pieces, and
+// wave tiling (4 waves x 128 f columns x all KP) as the float32 kernel.  One k-step = 16 rows = one MFMA depth;
+// per k-step a wave issues 4 loads of 1 KiB (one per 32-column tile) and 4*KT MFMAs.  Ring of BF_RING k-steps
+// (16 loads, 64 VGPRs, 16 KiB per wave in flight); one panel stage (64 rows) per ring pass, one barrier per stage.
+constexpr int BF_RING = 4;                 // k-steps per panel stage = prefetch distance
+constexpr int BF_ROWS = 16 * BF_RING;      // 64 rows per stage == SG_ROW_ALIGN
+
+template <int KT, bool LAST>
+__device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RING][4], const unsigned short* __restrict__ lrow,
+                                         const unsigned short* __restrict__ xnext, int64_t f_stride8)
+{
+    constexpr int KP = 32 * KT;
+    u32x4 a[2][KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(lrow + (32 * m) * 8);
+#pragma unroll
+    for (int p = 0; p < BF_RING; ++p) {
+        if (p + 1 < BF_RING) {
+#pragma unroll
+            for (int m = 0; m < KT; ++m)
+                a[(p + 1) & 1][m] = *reinterpret_cast<const u32x4*>(lrow + ((2 * (p + 1)) * KP + 32 * m) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[p & 1][m]),
+                                                                    __builtin_bit_cast(bf16x8, x[p][j]), acc[m][j], 0, 0, 0);
+        if (!LAST) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                x[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xnext + (2 * p) * f_stride8 + j * (32 * 8)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(SG_THREADS, (KT <= 2 ? 2 : 1))
+void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, const unsigned short* __restrict__ P,
+                             float* __restrict__ pieces, SweepGeom g)
+{
+    constexpr int KP = 32 * KT;
+    constexpr int STAGE_BF16 = BF_ROWS * KP;                        // bf16 elements of one panel stage
+    constexpr int PV = STAGE_BF16 / 8 / SG_THREADS;                 // 16-byte granules per thread per stage (= KT)
+    static_assert(STAGE_BF16 / 8 % SG_THREADS == 0, "panel stage must tile the workgroup exactly");
+    static_assert(BF_ROWS == SG_ROW_ALIGN, "stream-K spans are multiples of one stage");
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][STAGE_BF16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int w = blockIdx.x;
+    const int64_t total = (int64_t)g.nft * g.R;
+    int64_t pos = (int64_t)w * g.L;
+    const int64_t pos_end = min(total, pos + g.L);
+    const int first_tile = (int)(pos / g.R);
+    const int64_t f_stride8 = (int64_t)g.F * 8;                     // bf16 elements between consecutive 8-row blocks of S
+
+    u32x4 preg[PV];
+    u32x4 x[BF_RING][4];
+
+    while (pos < pos_end) {
+        const int ft = (int)(pos / g.R);
+        const int r_begin = (int)(pos - (int64_t)ft * g.R);
+        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
+        pos += r_end - r_begin;
+        const int nst = (r_end - r_begin) / BF_ROWS;
+        const int f0 = (ft * SG_WAVES + wave) * SG_WAVE_F;
+        const bool active = f0 < g.F;
+
+        const unsigned short* pptr = P + (int64_t)(r_begin / 8) * KP * 8 + 8 * tid;
+        auto load_p = [&](int t) {
+            const unsigned short* q = pptr + (int64_t)t * STAGE_BF16;
+#pragma unroll
+            for (int v = 0; v < PV; ++v) preg[v] = *reinterpret_cast<const u32x4*>(q + 8 * SG_THREADS * v);
+        };
+        auto store_p = [&](int b) {
+#pragma unroll
+            for (int v = 0; v < PV; ++v) *reinterpret_cast<u32x4*>(&lds[b][8 * (tid + SG_THREADS * v)]) = preg[v];
+        };
+
+        __syncthreads();
+        load_p(0);
+        store_p(0);
+        if (nst > 1) load_p(1);
+
+        if (!active) {
+            __syncthreads();
+            for (int t = 0; t + 1 < nst; ++t) {
+                store_p((t + 1) & 1);
+                if (t + 2 < nst) load_p(t + 2);
+                __syncthreads();
+            }
+            continue;
+        }
+
+        f32x16 acc[KT][4];
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+        // this lane's granule of (row block r_begin/8 + h, column f0 + c); tile j is +32 columns, k-step p is +2 blocks
+        const unsigned short* xrow = S + ((int64_t)(r_begin / 8 + h) * g.F + f0 + c) * 8;
+        const int64_t x_stage = (int64_t)(BF_ROWS / 8) * f_stride8;
+        const int lds_lane = (h * KP + c) * 8;
+
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < BF_RING; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                x[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xrow + (2 * p) * f_stride8 + j * (32 * 8)));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+
+        int t = 0;
+        for (; t + 2 < nst; ++t) {
+            store_p((t + 1) & 1);
+            load_p(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            bf_stage<KT, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8);
+            __syncthreads();
+        }
+        if (t + 1 < nst) {
+            store_p((t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            bf_stage<KT, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8);
+            __syncthreads();
+            ++t;
+        }
+        bf_stage<KT, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8);
+
+        // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = 128*wave + 32*j + c
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * SG_BLOCK_F + wave * SG_WAVE_F + c) * KP + 4 * h;
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = {acc[m][j][4 * q + 0], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(out + (int64_t)(32 * j) * KP + 32 * m + 8 * q) = v;
+                }
+    }
+}
+
+}  // namespace alpine

@@ -65,6 +65,7 @@ class ALPINE:
         eps: float = 1e-6,
         random_state: int = 42,
         shard_cells: bool = False,
+        x_dtype: str = "f32",
     ):
         self.n_components = n_components
         self.n_covariate_components = n_covariate_components
@@ -84,6 +85,11 @@ class ALPINE:
         # extension (not in the reference): shard the cell axis over the ranks of the default
         # torch.distributed process group, one process per GPU.  Default: single device.
         self.shard_cells = shard_cells
+        # extension: "bf16" stores X and the MFMA operand copies of W/H in bf16 (fp32 accumulation, fp32 master
+        # factors); default "f32" is the reference's arithmetic.
+        if x_dtype not in ("f32", "bf16"):
+            raise ValueError("x_dtype must be 'f32' or 'bf16'")
+        self.x_dtype = x_dtype
 
         self._validate_init_args()
 
@@ -170,7 +176,7 @@ class ALPINE:
         kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
-                  loss_type=self.loss_type, device_id=dev_index)
+                  loss_type=self.loss_type, device_id=dev_index, x_dtype=self.x_dtype)
         block = None
         if sharded:
             with torch.cuda.device(dev_index):
@@ -179,7 +185,7 @@ class ALPINE:
                 kw.update(stream=torch.cuda.current_stream().cuda_stream, reduce_block=block.data_ptr())
         eng = _native.NativeShard(**kw)
         try:
-            chunk = max(1, (1 << 28) // (4 * G))
+            chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)        # multiple of 8 cells (bf16 path packs 8 rows per granule)
             for r0 in range(c0, c1, chunk):
                 r1 = min(c1, r0 + chunk)
                 eng.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r1], dtype=np.float32), _native.X_CELLS_BY_GENES, r0 - c0)
@@ -253,9 +259,10 @@ class ALPINE:
         H0 = torch.rand((self.total_components, n_sample), dtype=torch.float32).numpy()
         W = np.ascontiguousarray(np.concatenate(self.matrices["Ws"], axis=1), dtype=np.float32)
         eng = _native.NativeShard(n_genes=G, n_cells=n_sample, n_components=self.total_components, cov_components=[],
-                                  cov_levels=[], lam=[], eps=self.eps, device_id=dev_index, transform_only=True)
+                                  cov_levels=[], lam=[], eps=self.eps, device_id=dev_index, transform_only=True,
+                                  x_dtype=self.x_dtype)
         try:
-            chunk = max(1, (1 << 28) // (4 * G))
+            chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)
             for r0 in range(0, n_sample, chunk):
                 eng.upload_X_host(np.ascontiguousarray(X[r0:r0 + chunk], dtype=np.float32), _native.X_CELLS_BY_GENES, r0)
             eng.finalize_X()

@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss", action="store_true", help="updates only (secondary number)")
     ap.add_argument("--cpu-sample-cells", type=int, default=6000)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage type of X and the MFMA operands (accumulation is f32)")
     ap.add_argument("--split-a", type=int, default=0)
     ap.add_argument("--split-b", type=int, default=0)
     return ap.parse_args()
@@ -165,7 +166,7 @@ def main():
 
     kw = dict(n_genes=G, n_cells=n_loc, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
               orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], eps=1e-6,
-              loss_type="kl-divergence", device_id=local_rank, split_a=args.split_a, split_b=args.split_b)
+              loss_type="kl-divergence", device_id=local_rank, split_a=args.split_a, split_b=args.split_b, x_dtype=args.dtype)
     block = None
     if world > 1:
         nfl = _native.reduce_block_floats(G, n_loc, ku, kcov, levels)
@@ -230,13 +231,13 @@ def main():
         launches = n_a + n_b
         avg_ms = (ms_a + ms_b) / max(1, launches)
         flops_per_launch = 2.0 * G * n_loc * K                    # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
-        bytes_per_launch = 4.0 * G * n_loc                        # X read once per sweep
+        bytes_per_launch = (4.0 if args.dtype == "f32" else 2.0) * G * n_loc      # X read once per sweep
         ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "NMF update iterations/sec (20k genes x 200k cells, K=50)",
             "value": it_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype if args.dtype == "f32" else "bf16 operands, f32 accumulate", "data": "synthetic",
             "config": {
                 "workload": (f"{args.workload}: {G} genes x {N} cells, K={ku}+{kcov} (K={K}), {len(kcov)} two-level covariates, "
                              f"lam=1e3, alpha_W={wl['alpha_W']}, orth_W={wl['orth_W']}, l1_ratio_W={wl['l1_ratio_W']}, KL loss, "
@@ -245,19 +246,23 @@ def main():
                 "grid_xht": info.grid_a, "grid_wtx": info.grid_b, "device_GiB": round(info.device_bytes / 2**30, 2),
                 "parallelism": f"cells/{world}",
             },
-            "roofline": {
-                "kernel": "stream_gemm_kernel (MFMA f32 32x32x2; XH^T and W^TX sweeps)",
-                "bound": "mfma", "achieved": ach_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": (pmc_traffic(args.workload, world, info.k_padded) or {}).get("bytes_per_launch") if not (args.cells or args.genes) else None,
-                "traffic_detail": pmc_traffic(args.workload, world, info.k_padded) if not (args.cells or args.genes) else None,
+            "roofline": (lambda mf: {
+                "kernel": ("stream_gemm_kernel (MFMA f32 32x32x2; XH^T and W^TX sweeps)" if mf else
+                           "stream_gemm_bf16_kernel (MFMA bf16 32x32x16, k-packed X; XH^T and W^TX sweeps)"),
+                "bound": "mfma" if mf else "hbm",
+                "achieved": ach_tf if mf else bytes_per_launch / (avg_ms * 1e-3) / 1e9,
+                "peak": FP32_MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBPS,
+                "unit": "TFLOP/s" if mf else "GB/s",
+                "frac": (ach_tf / FP32_MFMA_PEAK_TFLOPS) if mf else bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "traffic": (pmc_traffic(args.workload, world, info.k_padded) or {}).get("bytes_per_launch") if (mf and not (args.cells or args.genes)) else None,
+                "traffic_detail": pmc_traffic(args.workload, world, info.k_padded) if (mf and not (args.cells or args.genes)) else None,
                 "avg_launch_ms": avg_ms, "launches": launches,
                 "avg_ms_xht": ms_a / max(1, n_a), "avg_ms_wtx": ms_b / max(1, n_b),
                 "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "hbm_achieved_GBps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                "tflops": ach_tf, "hbm_achieved_GBps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                 "hbm_frac_of_8TBps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if avg_ms > 0 else 0.0,
                 "sweeps_share_of_step": (ms_a + ms_b) / (1e3 * dt) if dt > 0 else 0.0,
-            },
+            })(args.dtype == "f32"),
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
             "setup_s": t_gen,
         }

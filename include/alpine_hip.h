@@ -44,7 +44,14 @@ typedef enum {
 enum { ALPINE_LOSS_KL = 0, ALPINE_LOSS_FROBENIUS = 1 };      /* main.py:57, :371 */
 /* alpine_config.flags: a ctx that will only run alpine_transform keeps a single copy of X (genes x cells) and no
  * resources of the XH^T sweep; alpine_iter_begin / alpine_run then fail with ALPINE_ERR_STATE. */
-enum { ALPINE_FLAG_TRANSFORM_ONLY = 1 };
+enum {
+    ALPINE_FLAG_TRANSFORM_ONLY = 1,
+    /* bf16 storage path: both resident copies of X and the MFMA operand copies of W / H are bf16 (k-packed for
+     * v_mfma_f32_32x32x16_bf16), accumulation and all factor updates stay float32.  X chunks must start at a cell
+     * index that is a multiple of 8.  Halves the HBM traffic of the two sweeps; tolerance vs the float32 path is
+     * reported by the tests. */
+    ALPINE_FLAG_X_BF16 = 2
+};
 enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
 
 /* Constructor arguments of ALPINE (main.py:47-61) plus the shard geometry. */

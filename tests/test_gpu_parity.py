@@ -327,3 +327,64 @@ def test_transform_before_fit_raises():
     c = load_case("kl_1cov")
     with pytest.raises(RuntimeError, match="Model is not trained yet"):
         ALPINE(device="cuda", **c.params).transform(MiniAnnData(c.X, c.obs))
+
+
+# ------------------------------------------------------------------ bf16 storage path (BASELINE config 5)
+def bf16_round(a):
+    """numpy model of round-to-nearest-even float32 -> bf16 -> float32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+@pytest.mark.parametrize("name", ["kl_1cov", "ragged", "k74", "k105", "counts_2cov"])
+def test_bf16_sweeps_match_rounded_operands(name):
+    """The bf16 path must compute EXACTLY the float32-accumulated products of the bf16-rounded operands:
+    XH^T (phase 1) and, through one H update, W^TX.  Checked against float64 numpy on the rounded inputs."""
+    nat = _native()
+    c = load_case(name)
+    eng = make_engine(c, x_dtype="bf16")
+    info = eng.info()
+    G, N, K, KP = c.X.shape[1], c.X.shape[0], info.k_total, info.k_padded
+    Xr, Hr = bf16_round(c.X).astype(np.float64), bf16_round(c.H0).astype(np.float64)
+    assert abs(info.x_sqnorm - float(np.sum(Xr ** 2))) <= 1e-9 * info.x_sqnorm
+    eng.iter_begin()
+    blk = eng.read_buffer(nat.BUF_REDUCE_BLOCK, 0, info.genes_padded * KP).reshape(info.genes_padded, KP)
+    assert rel_fro(blk[:G, :K], Xr.T @ Hr.T) < 3e-6
+    assert not blk[G:].any() and not blk[:, K:].any()
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "ragged", "k105", "counts_2cov"])
+def test_bf16_fit_tolerance_vs_fp32_reference(name, record_property):
+    """Whole fits with bf16 operands vs the reference's float32 result: tolerance REPORTED (and bounded)."""
+    c = load_case(name)
+    eng = make_engine(c, x_dtype="bf16")
+    eng.run(c.T, with_loss=True)
+    W, H, Bs = eng.get_factors()
+    losses = eng.losses()
+    eng.close()
+    eW, eH = rel_fro(W, c.WT_unscaled), rel_fro(H, c.HT_unscaled)
+    eL = float(np.max(np.abs(losses[:, 1] - c.loss_history[:, 1]) / c.loss_history[:, 1]))
+    from oracle.alpine_oracle import recon_loss_f64
+    host = recon_loss_f64(np.ascontiguousarray(c.X.T), W, H)
+    ref = recon_loss_f64(np.ascontiguousarray(c.X.T), c.WT_unscaled, c.HT_unscaled)
+    print(f"bf16 vs fp32 reference [{name}]: rel-Fro dW={eW:.2e} dH={eH:.2e} max rel d(recon loss row)={eL:.2e} "
+          f"final recon (true X, fp64) {host:.6g} vs {ref:.6g} ({abs(host - ref) / ref:.2e})")
+    assert eW < 3e-2 and eH < 3e-2
+    assert abs(host - ref) / ref < 2e-3
+    assert (W >= 0).all() and (H >= 0).all() and np.isfinite(losses).all()
+
+
+def test_bf16_drop_in_and_transform():
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case("kl_2cov_nan")
+    adata = MiniAnnData(c.X.copy(), c.obs.copy())
+    model = ALPINE(device="cuda", x_dtype="bf16", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
+    H = np.concatenate(model.matrices["Hs"], axis=0)
+    assert rel_fro(H, c.HT) < 3e-2
+    n_t = (2 * c.X.shape[0]) // 3
+    a_t = MiniAnnData(c.X[:n_t].copy(), c.obs.iloc[:n_t].copy())
+    model.transform(a_t, n_iter=c.transform_iters)
+    Ht = np.concatenate([a_t.obsm[k].T for k in c.keys] + [a_t.obsm["ALPINE_embedding"].T], axis=0)
+    assert rel_fro(Ht, c.H_transform) < 5e-2
