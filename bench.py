@@ -110,17 +110,20 @@ def cpu_baseline(wl: dict, sample_cells: int, full_cells: int) -> dict:
     }
 
 
-def pmc_traffic(workload: str, world: int, kp: int):
+def pmc_traffic(workload: str, world: int, kp: int, dtype: str = "f32"):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (collected in separate
     runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md); None when no matching profile exists."""
     import glob
     if world != 1:
         return None
     best = None
-    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", f"{workload}_stream_gemm_pmc_summary.json"))):
+    import re
+    tag = "" if dtype == "f32" else "_bf16"
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", f"{workload}{tag}_stream_gemm_pmc_summary.json"))):
         try:
             d = json.load(open(f))
-            if d.get("kernel", "").endswith(f"<{kp // 32}>"):
+            m = re.search(r"<(\d+)", d.get("kernel", ""))
+            if m and int(m.group(1)) == kp // 32:
                 best = {"bytes_per_launch": d["traffic_bytes_per_launch"], "over_algorithmic": d["traffic_over_algorithmic"],
                         "source": os.path.relpath(f, REPO)}
         except (OSError, ValueError, KeyError):
@@ -254,8 +257,8 @@ def main():
                 "peak": FP32_MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBPS,
                 "unit": "TFLOP/s" if mf else "GB/s",
                 "frac": (ach_tf / FP32_MFMA_PEAK_TFLOPS) if mf else bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "traffic": (pmc_traffic(args.workload, world, info.k_padded) or {}).get("bytes_per_launch") if (mf and not (args.cells or args.genes)) else None,
-                "traffic_detail": pmc_traffic(args.workload, world, info.k_padded) if (mf and not (args.cells or args.genes)) else None,
+                "traffic": (pmc_traffic(args.workload, world, info.k_padded, args.dtype) or {}).get("bytes_per_launch") if not (args.cells or args.genes) else None,
+                "traffic_detail": pmc_traffic(args.workload, world, info.k_padded, args.dtype) if not (args.cells or args.genes) else None,
                 "avg_launch_ms": avg_ms, "launches": launches,
                 "avg_ms_xht": ms_a / max(1, n_a), "avg_ms_wtx": ms_b / max(1, n_b),
                 "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
