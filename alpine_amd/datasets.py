@@ -27,19 +27,22 @@ def synth_labels_host(n_cells: int, levels, seed: int = 1) -> np.ndarray:
 
 
 def synth_counts_device_chunks(n_cells: int, n_genes: int, rank: int, seed: int, device,
-                               chunk_cells: int = 16384, cell_offset: int = 0):
-    """Yield ``(cell0, X_chunk)`` with ``X_chunk`` a (chunk x genes) float32 torch tensor on
-    ``device``.  ``S`` is drawn once from ``seed``; ``A`` rows are drawn per chunk from a
-    generator keyed by (seed, global cell index of the chunk) so that any sharding of the
-    cell axis sees the same matrix."""
+                               chunk_cells: int = 8192, cell_offset: int = 0):
+    """Yield ``(local_cell0, X_chunk)`` for the cells ``[cell_offset, cell_offset + n_cells)`` of ONE global synthetic
+    matrix, with ``X_chunk`` a (rows x genes) float32 torch tensor on ``device``.  ``S`` is drawn once from ``seed``;
+    cells are generated in fixed GLOBAL blocks of ``chunk_cells`` cells, each from a generator keyed by (seed, global
+    block index), so every sharding of the cell axis sees the identical matrix (a shard that starts or ends inside
+    a block generates the whole block and keeps its rows)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    conc_s = torch.full((rank, n_genes), 0.3, device=device)
-    S = torch._standard_gamma(conc_s, generator=g) / (0.09 * rank)
-    for c0 in range(0, n_cells, chunk_cells):
-        c1 = min(n_cells, c0 + chunk_cells)
+    S = torch._standard_gamma(torch.full((rank, n_genes), 0.3, device=device), generator=g) / (0.09 * rank)
+    c_lo, c_hi = cell_offset, cell_offset + n_cells
+    for blk in range(c_lo // chunk_cells, (c_hi + chunk_cells - 1) // chunk_cells):
+        b0 = blk * chunk_cells
         gc = torch.Generator(device=device)
-        gc.manual_seed(seed * 1_000_003 + (cell_offset + c0) + 1)
-        A = torch._standard_gamma(torch.full((c1 - c0, rank), 0.3, device=device), generator=gc)
-        yield c0, torch.poisson(A @ S, generator=gc)
+        gc.manual_seed(seed * 1_000_003 + blk + 1)
+        A = torch._standard_gamma(torch.full((chunk_cells, rank), 0.3, device=device), generator=gc)
+        Xb = torch.poisson(A @ S, generator=gc)
+        lo, hi = max(c_lo, b0), min(c_hi, b0 + chunk_cells)
+        yield lo - c_lo, Xb[lo - b0:hi - b0]

@@ -177,12 +177,18 @@ class ALPINE:
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
                   loss_type=self.loss_type, device_id=dev_index, x_dtype=self.x_dtype)
-        block = None
+        block, stream = None, None
         if sharded:
+            # The engine and the collective must share ONE explicit stream: the default stream's handle is 0, which
+            # the C ABI reads as "create a private stream", and that would leave the all-reduce unordered with the kernels.
             with torch.cuda.device(dev_index):
+                stream = torch.cuda.Stream()
                 nfl = _native.reduce_block_floats(G, n_loc, self.n_components, self.n_covariate_components, cov_levels)
-                block = torch.zeros(nfl, dtype=torch.float32, device=f"cuda:{dev_index}")
-                kw.update(stream=torch.cuda.current_stream().cuda_stream, reduce_block=block.data_ptr())
+                with torch.cuda.stream(stream):
+                    block = torch.zeros(nfl, dtype=torch.float32, device=f"cuda:{dev_index}")
+                stream.synchronize()
+                kw.update(stream=stream.cuda_stream, reduce_block=block.data_ptr())
+                assert stream.cuda_stream != 0
         eng = _native.NativeShard(**kw)
         try:
             chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)        # multiple of 8 cells (bf16 path packs 8 rows per granule)
@@ -194,7 +200,8 @@ class ALPINE:
                 eng.upload_Y(i, np.ascontiguousarray(y[c0:c1].T))
             eng.set_factors(W0, H0, B0, h_col0=c0)
             if sharded:
-                ShardedLoop(eng, TorchDistComm(block)).run(n_iter, with_loss=True)
+                with torch.cuda.device(dev_index), torch.cuda.stream(stream):
+                    ShardedLoop(eng, TorchDistComm(block)).run(n_iter, with_loss=True)
             else:
                 eng.run(n_iter, with_loss=True)
             if scale:

@@ -149,11 +149,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    # rehearsal knob for a one-GPU box: all ranks share device 0 and gloo carries the (device) reduce block;
+    # the driver's multi-GPU runs never set it and use RCCL with one device per rank
+    rehearsal = os.environ.get("ALPINE_BENCH_REHEARSAL_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
     if args.cells:
@@ -170,16 +178,22 @@ def main():
     kw = dict(n_genes=G, n_cells=n_loc, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
               orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], eps=1e-6,
               loss_type="kl-divergence", device_id=local_rank, split_a=args.split_a, split_b=args.split_b, x_dtype=args.dtype)
-    block = None
+    block, stream = None, None
     if world > 1:
+        # engine kernels and the RCCL all-reduce share ONE explicit stream (the default stream's handle is 0, which the
+        # C ABI reads as "create a private stream" -- that would leave the collective unordered with the kernels)
+        stream = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(stream)
         nfl = _native.reduce_block_floats(G, n_loc, ku, kcov, levels)
         block = torch.zeros(nfl, dtype=torch.float32, device=dev)
-        kw.update(stream=torch.cuda.current_stream().cuda_stream, reduce_block=block.data_ptr())
+        stream.synchronize()
+        assert stream.cuda_stream != 0
+        kw.update(stream=stream.cuda_stream, reduce_block=block.data_ptr())
     eng = _native.NativeShard(**kw)
 
     # ---- synthetic input, generated on the device in cell chunks (never on the host)
     t_gen = time.perf_counter()
-    for off, chunk in synth_counts_device_chunks(n_loc, G, rank=ku, seed=0, device=dev, chunk_cells=16384, cell_offset=c0):
+    for off, chunk in synth_counts_device_chunks(n_loc, G, rank=ku, seed=0, device=dev, chunk_cells=8192, cell_offset=c0):
         torch.cuda.synchronize()
         eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
         eng.synchronize()

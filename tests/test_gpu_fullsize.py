@@ -28,7 +28,7 @@ def big():
         eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=KU, cov_components=KC, cov_levels=[2], lam=[lam],
                                   loss_type=loss_type)
         rowsum.zero_()
-        for off, chunk in synth_counts_device_chunks(N, G, rank=KU, seed=0, device=dev, chunk_cells=10000):
+        for off, chunk in synth_counts_device_chunks(N, G, rank=KU, seed=0, device=dev, chunk_cells=8192):
             torch.cuda.synchronize()
             eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
             eng.synchronize()
@@ -80,7 +80,7 @@ def test_exact_checksums_of_both_sweeps(big):
     dev = torch.device("cuda", 0)
     wt = torch.tensor(W1[:, 0], dtype=torch.float64, device=dev)
     want = torch.empty(N, dtype=torch.float64, device=dev)
-    for off, chunk in synth_counts_device_chunks(N, G, rank=KU, seed=0, device=dev, chunk_cells=10000):
+    for off, chunk in synth_counts_device_chunks(N, G, rank=KU, seed=0, device=dev, chunk_cells=8192):
         want[off:off + chunk.shape[0]] = chunk.double() @ wt
     want = want.cpu().numpy()
     assert np.allclose(wtx, want, rtol=5e-6)
