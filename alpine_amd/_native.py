@@ -23,7 +23,7 @@ EXPORTS = [
     "alpine_reduce_block_floats", "alpine_create", "alpine_destroy", "alpine_last_error", "alpine_get_info",
     "alpine_upload_X_host", "alpine_upload_X_device", "alpine_finalize_X", "alpine_upload_Y",
     "alpine_set_factors", "alpine_get_factors", "alpine_iter_begin", "alpine_iter_end", "alpine_reduce_block",
-    "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
+    "alpine_batch_step", "alpine_epoch_loss", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_get_kernel_time", "alpine_read_buffer",
 ]
 
@@ -37,7 +37,7 @@ class AlpineConfig(C.Structure):
         ("lam", C.POINTER(C.c_double)),
         ("orth_W", C.c_double), ("alpha_W", C.c_double), ("l1_ratio_W", C.c_double), ("eps", C.c_double),
         ("loss_type", C.c_int32), ("split_a", C.c_int32), ("split_b", C.c_int32), ("flags", C.c_int32),
-        ("stream", C.c_void_p), ("reduce_block", C.c_void_p),
+        ("stream", C.c_void_p), ("reduce_block", C.c_void_p), ("batch_capacity", C.c_int64),
     ]
 
 
@@ -88,6 +88,8 @@ def load() -> C.CDLL:
     lib.alpine_reduce_block.argtypes = [p, C.POINTER(p), C.POINTER(i64)]
     lib.alpine_run.argtypes = [p, i32, i32]
     lib.alpine_transform.argtypes = [p, i32]
+    lib.alpine_batch_step.argtypes = [p, p, i64]
+    lib.alpine_epoch_loss.argtypes = [p]
     lib.alpine_get_losses.argtypes = [p, C.POINTER(C.c_double), i64, C.POINTER(i64)]
     lib.alpine_reset_losses.argtypes = [p]
     lib.alpine_scale.argtypes = [p]
@@ -114,7 +116,8 @@ class NativeShard:
                  cov_levels: Sequence[int], lam: Sequence[float], orth_W: float = 0.0, alpha_W: float = 0.0,
                  l1_ratio_W: float = 0.0, eps: float = 1e-6, loss_type: str = "kl-divergence",
                  device_id: int = 0, stream: Optional[int] = None, reduce_block: Optional[int] = None,
-                 split_a: int = 0, split_b: int = 0, transform_only: bool = False, x_dtype: str = "f32"):
+                 split_a: int = 0, split_b: int = 0, transform_only: bool = False, x_dtype: str = "f32",
+                 batch_capacity: int = 0):
         if x_dtype not in ("f32", "bf16"):
             raise ValueError("x_dtype must be 'f32' or 'bf16'")
         self._lib = load()
@@ -134,6 +137,7 @@ class NativeShard:
         cfg.split_a, cfg.split_b, cfg.flags = split_a, split_b, ((FLAG_TRANSFORM_ONLY if transform_only else 0) | (FLAG_X_BF16 if x_dtype == "bf16" else 0))
         cfg.stream = stream
         cfg.reduce_block = reduce_block
+        cfg.batch_capacity = batch_capacity
         self._cfg = cfg
         self.n_genes, self.n_cells, self.n_cov = n_genes, n_cells, n_cov
         self.cov_components, self.cov_levels = list(cov_components), list(cov_levels)
@@ -217,6 +221,13 @@ class NativeShard:
 
     def run(self, n_iters: int, with_loss: bool = True):
         self._chk(self._lib.alpine_run(self._h, n_iters, 1 if with_loss else 0))
+
+    def batch_step(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        self._chk(self._lib.alpine_batch_step(self._h, idx.ctypes.data, idx.size))
+
+    def epoch_loss(self):
+        self._chk(self._lib.alpine_epoch_loss(self._h))
 
     def transform(self, n_iter: int):
         self._chk(self._lib.alpine_transform(self._h, n_iter))

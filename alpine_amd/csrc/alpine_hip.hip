@@ -17,6 +17,15 @@ using namespace alpine;
 
 static thread_local std::string g_create_error;
 
+// The cells an iteration works on: the whole shard, or a gathered mini-batch (main.py:509-521).
+struct CellView {
+    float *Xgn = nullptr, *Xng = nullptr, *H = nullptr, *Y = nullptr;
+    int N = 0;                // cells in the view
+    int64_t Np = 0;           // padded cells = leading dimension of Xgn / Y, rows of Xng / H
+    SweepGeom gA{}, gB{};
+    int statBlocks = 0, gramBlocksH = 0;
+};
+
 struct alpine_ctx {
     // geometry
     int G = 0, N = 0, K = 0, KP = 0, KT = 0, n_cov = 0;
@@ -38,6 +47,12 @@ struct alpine_ctx {
     bool bf16 = false;
     float *piecesA = nullptr, *piecesB = nullptr;     // stream-K partial results of the two sweeps
     SweepGeom geomA{}, geomB{};
+    CellView full{};                                  // the whole shard
+    // mini-batch view buffers (alpine_config.batch_capacity > 0)
+    int64_t batch_cap = 0;
+    float *Xb_gn = nullptr, *Xb_ng = nullptr, *Hb = nullptr, *Yb = nullptr;
+    int* idx_dev = nullptr;
+    int slots = 512;
     float* red = nullptr;
     bool own_red = false;
     int64_t red_floats = 0, red_hht = 0, red_stats = 0;
@@ -122,6 +137,7 @@ static int geometry(const alpine_config* cfg, Geometry* g, std::string* why)
 {
     if (!cfg || cfg->struct_size != (int32_t)sizeof(alpine_config)) { *why = "alpine_config.struct_size mismatch"; return -1; }
     if (cfg->n_genes <= 0 || cfg->n_cells <= 0) { *why = "n_genes and n_cells must be positive"; return -1; }
+    if (cfg->batch_capacity < 0) { *why = "batch_capacity must be >= 0"; return -1; }
     if (cfg->n_genes > (1 << 30) || cfg->n_cells > (1 << 30)) { *why = "n_genes / n_cells too large for this build"; return -1; }
     if (cfg->n_components <= 0) { *why = "n_components must be greater than 0."; return -1; }
     if (cfg->n_covariates < 0 || cfg->n_covariates > MAX_COV) { *why = "n_covariates out of range (0..16)"; return -1; }
@@ -219,6 +235,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
     // sweeps
     const int slots = c->n_cu * (c->KT <= 2 ? 2 : 1);
+    c->slots = slots;
+    c->batch_cap = cfg->batch_capacity;
     c->geomA = make_geom(Gp, Np, slots, cfg->split_a);       // XH^T: f = genes, r = cells
     c->geomB = make_geom(Np, Gp, slots, cfg->split_b);       // W^TX: f = cells, r = genes
 
@@ -261,6 +279,18 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->stage_floats = std::max<int64_t>((int64_t)1 << 26, std::max<int64_t>((int64_t)c->K * Np, Gp * (int64_t)KP));   // >= 256 MiB
     ALLOC(c, c->stage, float, c->stage_floats);
     c->x_seen.assign((size_t)((c->N + 1023) / 1024), 0);
+    c->full.Xgn = c->Xgn; c->full.Xng = c->Xng; c->full.H = c->H; c->full.Y = c->Y;
+    c->full.N = c->N; c->full.Np = Np; c->full.gA = c->geomA; c->full.gB = c->geomB;
+    c->full.statBlocks = c->statBlocks; c->full.gramBlocksH = c->gramBlocksH;
+    if (c->batch_cap > 0) {
+        if (c->bf16 || c->transform_only) return fail(c, ALPINE_ERR_UNSUPPORTED, "batch_capacity needs the float32 two-copy layout");
+        const int64_t Bp = round_up(std::min<int64_t>(c->batch_cap, (int64_t)1 << 30), 128);
+        ALLOC(c, c->Xb_gn, float, Gp * Bp);
+        ALLOC(c, c->Xb_ng, float, Bp * Gp);
+        ALLOC(c, c->Hb, float, Bp * KP);
+        ALLOC(c, c->Yb, float, (int64_t)std::max(1, c->nYrows) * Bp);
+        ALLOC(c, c->idx_dev, int, Bp);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // kind[] / lam[] host vectors go out of scope
     return 0;
 }
@@ -285,7 +315,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtW, c->Xgn16, c->Xng16, c->Wp16, c->Hp16, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtW, c->Xgn16, c->Xng16, c->Wp16, c->Hp16, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -553,9 +583,9 @@ static int launch_sweep_bf16(alpine_ctx* c, int which)
     return 0;
 }
 
-static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces)
+static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which)
 {
-    if (c->bf16) return launch_sweep_bf16(c, &g == &c->geomA ? 0 : 1);
+    if (c->bf16) return launch_sweep_bf16(c, which);
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
 #define SG_LAUNCH(RING, PASSES) \
     DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_kernel<KT_, RING, PASSES>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, P, pieces, ldS, g, (unsigned long long*)nullptr))
@@ -588,26 +618,24 @@ static int ready(alpine_ctx* c)
     return 0;
 }
 
-extern "C" int alpine_iter_begin(alpine_ctx* c)
+// phase 1 on a view: local sums of everything that depends on the old H of the view's cells -> reduce block
+static int phase1(alpine_ctx* c, const CellView& v)
 {
-    int rc = ready(c);
-    if (rc) return rc;
-    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
+    int rc;
     const int KP = c->KP;
     if (c->n_cov > 0) {
-        hipLaunchKernelGGL(hstats_kernel, dim3(c->statBlocks), dim3(HS_CELLS), 0, c->stream, c->H, c->Y, c->B[c->bcur], c->meta,
-                           c->statPart, c->N, c->Np, KP, (float)c->eps, c->nstat);
+        hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), 0, c->stream, v.H, v.Y, c->B[c->bcur], c->meta,
+                           c->statPart, v.N, v.Np, KP, (float)c->eps, c->nstat);
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,
-                       c->statBlocks, c->nstat, c->xnorm2);
+                       v.statBlocks, c->nstat, c->xnorm2);
     HIPCHK(c, hipGetLastError());
-    rc = launch_gram(c, c->H, c->Np, c->gramBlocksH, c->red + c->red_hht);
-    if (rc) return rc;
+    if ((rc = launch_gram(c, v.H, v.Np, v.gramBlocksH, c->red + c->red_hht))) return rc;
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-    if ((rc = launch_sweep(c, c->geomA, c->Xng, c->H, c->piecesA))) return rc;
+    if ((rc = launch_sweep(c, v.gA, v.Xng, v.H, c->piecesA, 0))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-    return launch_reduce_pieces(c, c->piecesA, c->red, (int)c->Gp, c->geomA);
+    return launch_reduce_pieces(c, c->piecesA, c->red, (int)c->Gp, v.gA);
 }
 
 static int grow_losses(alpine_ctx* c)
@@ -624,11 +652,11 @@ static int grow_losses(alpine_ctx* c)
     return 0;
 }
 
-extern "C" int alpine_iter_end(alpine_ctx* c, int update)
+// phase 2 on a view: [loss row of the factors that produced the reduce block], W update, B updates, W^TW, W^TX sweep,
+// H update of the view's cells.  finalize: append a loss row (the reduce block must then describe the FULL shard).
+static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
 {
-    int rc = ready(c);
-    if (rc) return rc;
-    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
+    int rc;
     const int KP = c->KP, K = c->K;
     const float l2 = (float)((1.0 - c->l1r) * c->alpha), l1 = (float)(c->l1r * c->alpha);
     const int wblocks = c->ndot / 4;
@@ -636,14 +664,13 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
     DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_kernel<KT_>, dim3(wblocks), dim3(256), m_bytes, c->stream, c->W, c->red,
                                            c->red + c->red_hht, c->dotpart, c->G, K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0));
     HIPCHK(c, hipGetLastError());
-    if (c->pending_loss && c->loss_enabled) {
+    if (finalize) {
         if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, c->red + c->red_hht,
                            c->red + c->red_stats, c->meta, c->nstat, KP, c->lam_dev, c->loss_dev + c->loss_rows * (c->n_cov + 2));
         HIPCHK(c, hipGetLastError());
         c->loss_rows++;
     }
-    c->pending_loss = false;
     if (!update) return 0;
 
     if (c->n_cov > 0) {
@@ -652,23 +679,99 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
         HIPCHK(c, hipGetLastError());
         c->bcur ^= 1;
     }
-    rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW);
-    if (rc) return rc;
+    if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    if ((rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB))) return rc;
+    if ((rc = launch_sweep(c, v.gB, v.Xgn, c->W, c->piecesB, 1))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
     const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
     if (c->h_update_valu) {           // reference implementation of the same update on the VALU (A/B and fallback)
-        const int hblocks = (int)((c->N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
-        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->piecesB, c->geomB,
-                                               c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
+        const int hblocks = (int)((v.N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
+                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
     } else {
-        const int hblocks = (int)((c->N + 127) / 128);
-        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, c->H, c->piecesB, c->geomB,
-                                               c->WtW, c->Y, c->B[c->bcur], c->meta, c->N, c->Np, K, (float)c->eps, c->nB));
+        const int hblocks = (int)((v.N + 127) / 128);
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
+                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
     }
     HIPCHK(c, hipGetLastError());
-    c->pending_loss = true;
+    return 0;
+}
+
+extern "C" int alpine_iter_begin(alpine_ctx* c)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
+    return phase1(c, c->full);
+}
+
+extern "C" int alpine_iter_end(alpine_ctx* c, int update)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
+    rc = phase2(c, c->full, update != 0, c->pending_loss && c->loss_enabled);
+    if (rc) return rc;
+    c->pending_loss = update != 0;
+    return 0;
+}
+
+// One mini-batch update (main.py:512-663 for one batch): the n cells idx[0..n) (local indices, duplicates allowed:
+// "weighted" sampling draws with replacement) are gathered into a contiguous view, the same phase 1 / phase 2 kernels
+// run on the view, and the updated rows of H are scattered back.
+extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only || c->bf16) return fail(c, ALPINE_ERR_UNSUPPORTED, "mini-batches need the float32 two-copy layout");
+    if (!idx || n <= 0 || n > c->batch_cap) return fail(c, ALPINE_ERR_BAD_ARG, "batch of %lld cells outside the ctx's batch_capacity %lld", (long long)n, (long long)c->batch_cap);
+    std::vector<int> h((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        if (idx[j] < 0 || idx[j] >= c->N) return fail(c, ALPINE_ERR_BAD_ARG, "batch index %lld out of range", (long long)idx[j]);
+        h[(size_t)j] = (int)idx[j];
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // idx_dev may still be read by the previous batch's scatter
+    HIPCHK(c, hipMemcpy(c->idx_dev, h.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    const int KP = c->KP, G = c->G;
+    const int64_t Bp = round_up(n, 128);
+    const int nb = c->n_cu * 8;
+    // gather the view: rows of the cells x genes copy, rows of H, columns of Y; then the genes x cells copy by transpose
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Xng, c->Gp, c->idx_dev, (int)n, (int)Bp, c->Xb_ng, c->Gp, (int)c->Gp);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->H, (int64_t)KP, c->idx_dev, (int)n, (int)Bp, c->Hb, (int64_t)KP, KP);
+    if (c->nYrows > 0)
+        hipLaunchKernelGGL(gather_cols_kernel, dim3(nb), dim3(256), 0, c->stream, c->Y, c->Np, c->idx_dev, (int)n, (int)Bp, c->Yb, Bp, c->nYrows);
+    {
+        dim3 grid((unsigned)((c->Gp + 31) / 32), (unsigned)((Bp + 31) / 32));
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->Xb_ng, c->Gp, c->Xb_gn, Bp, (int)Bp, (int)c->Gp);
+    }
+    HIPCHK(c, hipGetLastError());
+    (void)G;
+    CellView v;
+    v.Xgn = c->Xb_gn; v.Xng = c->Xb_ng; v.H = c->Hb; v.Y = c->Yb;
+    v.N = (int)n; v.Np = Bp;
+    v.gA = make_geom(c->Gp, Bp, c->slots, 0);
+    v.gB = make_geom(Bp, c->Gp, c->slots, 0);
+    v.statBlocks = (int)((n + HS_CELLS - 1) / HS_CELLS);
+    v.gramBlocksH = (int)((Bp + 4 * GR_ROWS_PER_WAVE - 1) / (4 * GR_ROWS_PER_WAVE));
+    if ((rc = phase1(c, v))) return rc;
+    if ((rc = phase2(c, v, true, false))) return rc;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Hb, (int64_t)KP, c->idx_dev, (int)n, c->H, (int64_t)KP, KP);
+    HIPCHK(c, hipGetLastError());
+    c->pending_loss = false;
+    return 0;
+}
+
+// Loss row of the CURRENT factors over the whole shard (main.py:666 after the batches of an epoch): full-view phase 1,
+// <XH^T, W> partials, trace-form finalise.  W^TW must be that of the current W (it is, after any update step).
+extern "C" int alpine_epoch_loss(alpine_ctx* c)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
+    if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
+    if ((rc = phase1(c, c->full))) return rc;
+    if ((rc = phase2(c, c->full, false, true))) return rc;
+    c->pending_loss = false;
     return 0;
 }
 
@@ -680,7 +783,7 @@ extern "C" int alpine_transform(alpine_ctx* c, int n_iter)
     const int KP = c->KP;
     if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    if ((rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB))) return rc;
+    if ((rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB, 1))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
     const int hblocks = (int)((c->N + 127) / 128);
     DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_iterate_mfma_kernel<KT_>, dim3(hblocks), dim3(256), sizeof(float) * KP * KP, c->stream, c->H,

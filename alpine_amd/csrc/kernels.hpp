@@ -1013,6 +1013,42 @@ __global__ void unpad_rows_kernel(const float* __restrict__ src, int KP, float* 
 }
 
 // ----------------------------------------------------------------------------------------------
+// mini-batch views (main.py:509-521): dst[j][0:width] = j < n ? src[idx[j]][0:width] : 0 for j < n_pad
+// (width multiple of 4), the column gather of Y, and the row scatter of the updated H (main.py:659-663; duplicate
+// indices of a batch carry identical rows, so the write order does not matter).
+__global__ __launch_bounds__(256)
+void gather_rows_kernel(const float* __restrict__ src, int64_t ld_src, const int* __restrict__ idx, int n, int n_pad,
+                        float* __restrict__ dst, int64_t ld_dst, int width)
+{
+    const int w4 = width / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)n_pad * w4; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i / w4), q = (int)(i % w4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < n) v = *reinterpret_cast<const f32x4*>(src + (int64_t)idx[j] * ld_src + 4 * q);
+        *reinterpret_cast<f32x4*>(dst + (int64_t)j * ld_dst + 4 * q) = v;
+    }
+}
+__global__ __launch_bounds__(256)
+void gather_cols_kernel(const float* __restrict__ src, int64_t ld_src, const int* __restrict__ idx, int n, int n_pad,
+                        float* __restrict__ dst, int64_t ld_dst, int rows)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * n_pad; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / n_pad), j = (int)(i % n_pad);
+        dst[(int64_t)r * ld_dst + j] = j < n ? src[(int64_t)r * ld_src + idx[j]] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256)
+void scatter_rows_kernel(const float* __restrict__ src, int64_t ld_src, const int* __restrict__ idx, int n,
+                         float* __restrict__ dst, int64_t ld_dst, int width)
+{
+    const int w4 = width / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)n * w4; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i / w4), q = (int)(i % w4);
+        *reinterpret_cast<f32x4*>(dst + (int64_t)idx[j] * ld_dst + 4 * q) = *reinterpret_cast<const f32x4*>(src + (int64_t)j * ld_src + 4 * q);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // scaling, main.py:772-781
 __global__ __launch_bounds__(256)
 void colsum_part_kernel(const float* __restrict__ W, int KP, int G, int rows_per_block, double* __restrict__ part)

@@ -145,12 +145,19 @@ class ALPINE:
     def _check_supported(self, n_sample: int) -> None:
         if self.use_als:
             raise NotImplementedError("use_als=True (block-coordinate branch, main.py:523-588) is not part of the accelerated path yet")
-        if self.batch_size < n_sample:
-            raise NotImplementedError("mini-batch fitting (batch_size < n_cells, main.py:509-521) is not part of the accelerated path yet")
-        if self.sampling_method != "random":
-            if self.sampling_method == "weighted":
-                raise NotImplementedError("sampling_method='weighted' is not part of the accelerated path yet")
+        if self.sampling_method not in ("random", "weighted"):
             raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
+        if self._uses_batches(n_sample):
+            if self.shard_cells:
+                raise NotImplementedError("mini-batch / weighted sampling is single-device for now (no shard_cells)")
+            if self.x_dtype != "f32":
+                raise NotImplementedError("mini-batch / weighted sampling needs x_dtype='f32'")
+
+    def _uses_batches(self, n_sample: int) -> bool:
+        """Full batch with the 'random' permutation is the in-place fast path (the permutation only re-orders sums);
+        anything else changes the mathematics (stochastic W updates, or duplicates under weighted resampling) and goes
+        through the gathered mini-batch view."""
+        return self.batch_size < n_sample or self.sampling_method == "weighted"
 
     def _run_native(self, X_cells_genes: np.ndarray, Y: List[np.ndarray], n_iter: int, scale: bool) -> dict:
         """Upload, initialise exactly like main.py:436-472, run the MU loop on the device(s), read back."""
@@ -176,7 +183,8 @@ class ALPINE:
         kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
-                  loss_type=self.loss_type, device_id=dev_index, x_dtype=self.x_dtype)
+                  loss_type=self.loss_type, device_id=dev_index, x_dtype=self.x_dtype,
+                  batch_capacity=(min(self.batch_size, N_total) if self._uses_batches(N_total) else 0))
         block, stream = None, None
         if sharded:
             # The engine and the collective must share ONE explicit stream: the default stream's handle is 0, which
@@ -199,7 +207,9 @@ class ALPINE:
             for i, y in enumerate(Y):
                 eng.upload_Y(i, np.ascontiguousarray(y[c0:c1].T))
             eng.set_factors(W0, H0, B0, h_col0=c0)
-            if sharded:
+            if kw.get("batch_capacity", 0) > 0:
+                self._run_epochs(eng, Y, N_total, n_iter)
+            elif sharded:
                 with torch.cuda.device(dev_index), torch.cuda.stream(stream):
                     ShardedLoop(eng, TorchDistComm(block)).run(n_iter, with_loss=True)
             else:
@@ -285,6 +295,35 @@ class ALPINE:
             adata.varm[covariate] = deepcopy(self.matrices["Ws"][i])
         adata.obsm["ALPINE_embedding"] = np.ascontiguousarray(Hs[-1].T)
         adata.varm["ALPINE_weights"] = deepcopy(self.matrices["Ws"][-1])
+
+    # ----------------------------------------- mini-batch epochs (main.py:500-521, sampling.py:6-71)
+    @staticmethod
+    def _balanced_joint_weights(Y: List[np.ndarray]) -> np.ndarray:
+        """sampling.py:36-55 + sklearn compute_sample_weight("balanced"): a cell's joint label is the tuple of its
+        argmax level per covariate (an all-zero NaN row has argmax 0); weight = n / (n_classes * count(label))."""
+        codes = np.stack([np.argmax(y, axis=1) for y in Y], axis=1)
+        _, inv, cnt = np.unique(codes, axis=0, return_inverse=True, return_counts=True)
+        inv = np.asarray(inv).reshape(-1)
+        return (codes.shape[0] / (len(cnt) * cnt.astype(np.float64)))[inv]
+
+    def _run_epochs(self, eng, Y: List[np.ndarray], n_total: int, n_iter: int) -> None:
+        """The epoch/batch structure of main.py:500-521 with the reference's own index streams (drawn from the global
+        torch generator right after the init draws): 'random' = torch.randperm(N) (sampling.py:14); 'weighted' =
+        WeightedRandomSampler(weights, N, replacement=True) == torch.multinomial(weights as float64, N, True)
+        (sampling.py:18-33).  Each batch is one alpine_batch_step; one loss row over all cells per epoch."""
+        self._rng_replay = None                                     # the stream is consumed for real here
+        weights = None
+        if self.sampling_method == "weighted":
+            weights = torch.as_tensor(self._balanced_joint_weights(Y), dtype=torch.double)
+        bs = self.batch_size
+        for _ in range(n_iter):
+            if weights is not None:
+                epoch = torch.multinomial(weights, n_total, True).numpy()
+            else:
+                epoch = torch.randperm(n_total).numpy()
+            for b0 in range(0, n_total, bs):
+                eng.batch_step(epoch[b0:min(b0 + bs, n_total)])
+            eng.epoch_loss()
 
     # ------------------------------------------------- store_embeddings (main.py:303-320)
     def store_embeddings(self, adata) -> None:

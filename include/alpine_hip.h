@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALPINE_HIP_ABI_VERSION 1
+#define ALPINE_HIP_ABI_VERSION 2
 
 typedef struct alpine_ctx alpine_ctx;
 
@@ -76,6 +76,8 @@ typedef struct {
     void* stream;                   /* hipStream_t to enqueue on, NULL = the library creates one */
     void* reduce_block;             /* optional device buffer of alpine_reduce_block_floats() floats that the
                                        caller owns (e.g. a torch tensor it will all-reduce); NULL = library allocates */
+    int64_t batch_capacity;         /* > 0: allocate the mini-batch view for up to this many cells per alpine_batch_step
+                                       (batch_size of ALPINE.fit, main.py:86, :112); 0 = full batch only */
 } alpine_config;
 
 typedef struct {
@@ -130,6 +132,14 @@ int alpine_get_factors(alpine_ctx* ctx, float* W, float* H, int64_t ldH, float* 
 int alpine_iter_begin(alpine_ctx* ctx);
 int alpine_iter_end(alpine_ctx* ctx, int update);
 int alpine_reduce_block(alpine_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+
+/* Mini-batch fitting (main.py:509-521, :512-663; alpine/utils/sampling.py:58-71): the caller draws the epoch's index
+ * stream exactly as the reference does (torch.randperm, or the weighted sampler with replacement) and feeds it one batch
+ * at a time.  alpine_batch_step gathers the n cells idx[0..n) of the local shard into a contiguous view, runs the W, B
+ * and H updates on that view and scatters the updated columns of H back (replaces X[:, idx] / H[:, idx] = ...).
+ * alpine_epoch_loss appends the loss row of the current factors over ALL cells (main.py:666).  float32 layout only. */
+int alpine_batch_step(alpine_ctx* ctx, const int64_t* idx, int64_t n);
+int alpine_epoch_loss(alpine_ctx* ctx);
 
 /* Replaces the loop of ALPINE._fit for one device (main.py:500-667): n_iters iterations; with_loss!=0
  * also produces one loss row per iteration ([total, recon, pred_1..pred_C], main.py:726-753). */

@@ -198,6 +198,32 @@ def fit_faithful(p: OracleParams, s: OracleState, max_iter: int, use_perm: bool 
     return s
 
 
+def balanced_joint_weights(Ys_cn: Sequence[torch.Tensor]) -> np.ndarray:
+    """alpine/utils/sampling.py:36-55 (joint label = argmax level of every covariate, NaN rows -> level 0) and
+    sklearn's compute_sample_weight("balanced") as used at sampling.py:23: n / (n_classes * count(label))."""
+    codes = np.stack([torch.argmax(y, dim=0).numpy() for y in Ys_cn], axis=1)
+    _, inv, cnt = np.unique(codes, axis=0, return_inverse=True, return_counts=True)
+    return (codes.shape[0] / (len(cnt) * cnt.astype(np.float64)))[np.asarray(inv).reshape(-1)]
+
+
+def fit_faithful_batches(p: OracleParams, s: OracleState, max_iter: int, batch_size: Optional[int],
+                         sampling_method: str = "random", with_loss: bool = True) -> OracleState:
+    """main.py:500-667 in full generality: per epoch one index stream (sampling.py:6-33: randperm, or the weighted
+    sampler with replacement = torch.multinomial on float64 weights), cut into batches (sampling.py:58-71); every
+    batch runs the MU step on the gathered columns and scatters H back; one loss row per epoch over all cells."""
+    N = s.X.shape[1]
+    bs = N if batch_size is None else batch_size
+    w = torch.as_tensor(balanced_joint_weights(s.Ys), dtype=torch.double) if sampling_method == "weighted" else None
+    with torch.no_grad():
+        for _ in range(max_iter):
+            epoch = torch.multinomial(w, N, True) if w is not None else torch.randperm(N)
+            for b0 in range(0, N, bs):
+                mu_step_faithful(p, s, epoch[b0:min(b0 + bs, N)])
+            if with_loss:
+                s.losses.append(loss_row(p, s))
+    return s
+
+
 # --------------------------------------------------------------------- fused step
 def fused_reduce_terms(p: OracleParams, s: OracleState):
     """Everything one iteration needs that is a SUM OVER CELLS of per-cell quantities of the

@@ -116,6 +116,16 @@ CASES = [
          covariates=[("cond", ["a", "b"], 0.0), ("batch", ["b0", "b1"], 0.0)],
          params=dict(n_components=12, n_covariate_components=[3, 3], lam=[1e3, 1e3],
                      alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5)),
+    # mini-batch and weighted sampling (main.py:509-521, sampling.py): stochastic W updates, duplicates under replacement
+    dict(name="mb_random", n_cells=96, n_genes=64, seed=10, T=12, fit_kwargs=dict(batch_size=32),
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[1e3])),
+    dict(name="mb_weighted", n_cells=150, n_genes=80, seed=11, T=10, fit_kwargs=dict(batch_size=40, sampling_method="weighted"),
+         covariates=[("c1", ["x", "y", "z"], 0.1), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=5, n_covariate_components=[2, 3], lam=[1e3, 5e2], alpha_W=0.3, orth_W=0.05, l1_ratio_W=0.5)),
+    dict(name="full_weighted", n_cells=96, n_genes=64, seed=12, T=10, fit_kwargs=dict(sampling_method="weighted"),
+         covariates=[("cond", ["a", "b", "c"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[10.0], loss_type="frobenius")),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,
@@ -139,7 +149,7 @@ def run_case(case: dict, AnnData, out_dir: str):
     def run(T, scale):
         a = AnnData(X.copy(), obs.copy())
         m = alpine.ALPINE(device="cpu", scale_needed=scale, **params)
-        m.fit(a, covariate_keys=keys, max_iter=T)
+        m.fit(a, covariate_keys=keys, max_iter=T, **case.get("fit_kwargs", {}))
         return m, a
 
     # init exactly as fit() produces it (main.py:135 -> :436-472)
@@ -181,6 +191,7 @@ def run_case(case: dict, AnnData, out_dir: str):
     meta = dict(
         name=case["name"], n_cells=case["n_cells"], n_genes=case["n_genes"], seed=case["seed"],
         T=case["T"], data=case.get("data", "gamma"), covariate_keys=keys, transform_iters=case.get("transform_iters", 0),
+        fit_kwargs=case.get("fit_kwargs", {}),
         covariates=[[k, lv, nf] for k, lv, nf in case["covariates"]],
         params=params, loss_columns=list(ms.loss_history.columns),
         encoded_labels=ms.fe.encoded_labels,

@@ -13,6 +13,7 @@ import pandas as pd
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SMALL_CASES = ["kl_1cov", "fro_1cov", "kl_reg", "kl_2cov_nan", "fro_2cov_reg", "ragged",
                "one_iter", "k74", "k105", "counts_2cov"]
+BATCH_CASES = ["mb_random", "mb_weighted", "full_weighted"]       # mini-batch / weighted sampling (stochastic)
 ALL_CASES = SMALL_CASES + ["cfg1"]
 
 
@@ -52,6 +53,7 @@ def load_case(name: str) -> SimpleNamespace:
         setattr(c, f"B{tag}", [z[f"B{tag}_{i}"] for i in range(n_cov)])
     c.Ys = [z[f"Y_{i}"] for i in range(n_cov)]          # C_i x N
     c.transform_iters = meta.get("transform_iters", 0)
+    c.fit_kwargs = meta.get("fit_kwargs", {})
     c.H_transform = z["H_transform"] if "H_transform" in z.files else None
     return c
 

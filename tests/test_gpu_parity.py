@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import ALL_CASES, SMALL_CASES, assert_loss_rows_close, load_case, rel_fro
+from _golden import ALL_CASES, BATCH_CASES, SMALL_CASES, assert_loss_rows_close, load_case, rel_fro
 
 pytestmark = pytest.mark.gpu
 
@@ -388,3 +388,57 @@ def test_bf16_drop_in_and_transform():
     model.transform(a_t, n_iter=c.transform_iters)
     Ht = np.concatenate([a_t.obsm[k].T for k in c.keys] + [a_t.obsm["ALPINE_embedding"].T], axis=0)
     assert rel_fro(Ht, c.H_transform) < 5e-2
+
+
+# ------------------------------------------------------------------ mini-batch / weighted sampling (next #2)
+@pytest.mark.parametrize("name", BATCH_CASES)
+def test_minibatch_drop_in_vs_reference(name):
+    """ALPINE.fit(batch_size=..., sampling_method=...) on the HIP path vs the reference: same index streams from the
+    global torch generator, per-batch gathered views, one loss row per epoch over all cells."""
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case(name)
+    adata = MiniAnnData(c.X.copy(), c.obs.copy())
+    model = ALPINE(device="cuda", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+    W = np.concatenate(model.matrices["Ws"], axis=1)
+    H = np.concatenate(model.matrices["Hs"], axis=0)
+    assert rel_fro(W, c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
+    for b, bt in zip(model.matrices["Bs"], c.BT):
+        assert rel_fro(b, bt) < 2e-4
+    assert_loss_rows_close(model.loss_history.to_numpy(), c.loss_history, n_cells=c.X.shape[0])
+    assert model.batch_size == c.fit_kwargs.get("batch_size", c.X.shape[0])
+
+
+def test_batch_step_full_identity_batch_equals_full_step():
+    """One alpine_batch_step over all cells in identity order == one in-place full-batch iteration."""
+    c = load_case("kl_2cov_nan")
+    n = c.X.shape[0]
+    a = make_engine(c)
+    a.run(1, with_loss=False)
+    Wa, Ha, Ba = a.get_factors()
+    a.close()
+    b = make_engine(c, batch_capacity=n)
+    b.batch_step(np.arange(n))
+    b.epoch_loss()
+    Wb, Hb, Bb = b.get_factors()
+    lb = b.losses()
+    b.close()
+    assert rel_fro(Wb, Wa) < 2e-6 and rel_fro(Hb, Ha) < 2e-6
+    for x, y in zip(Bb, Ba):
+        assert rel_fro(x, y) < 2e-6
+    from oracle.alpine_oracle import recon_loss_f64
+    assert abs(lb[0, 1] - recon_loss_f64(np.ascontiguousarray(c.X.T), Wb, Hb)) <= 2e-5 * lb[0, 1]
+
+
+def test_batch_step_argument_errors():
+    nat = _native()
+    c = load_case("kl_1cov")
+    eng = make_engine(c, batch_capacity=16)
+    with pytest.raises(nat.AlpineNativeError):
+        eng.batch_step(np.arange(17))             # larger than the capacity
+    with pytest.raises(nat.AlpineNativeError):
+        eng.batch_step(np.array([0, 1, 10 ** 6]))   # index outside the shard
+    eng.close()
+    eng = make_engine(c)                          # no batch view allocated
+    with pytest.raises(nat.AlpineNativeError):
+        eng.batch_step(np.arange(4))
+    eng.close()

@@ -177,7 +177,9 @@ def test_fit_rejects_non_anndata_and_unsupported_modes():
     with pytest.raises(NotImplementedError):
         ALPINE(use_als=True, **GOOD).fit(a, covariate_keys=["c"], max_iter=1)
     with pytest.raises(NotImplementedError):
-        ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, batch_size=5)
+        ALPINE(shard_cells=True, **GOOD).fit(a, covariate_keys=["c"], max_iter=1, batch_size=5)
+    with pytest.raises(NotImplementedError):
+        ALPINE(x_dtype="bf16", **GOOD).fit(a, covariate_keys=["c"], max_iter=1, sampling_method="weighted")
     with pytest.raises(ValueError, match="Unknown sampling method"):
         ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, sampling_method="bogus")
 
