@@ -79,6 +79,7 @@ struct alpine_ctx {
     // results, prices the HBM stream against the MFMA pipeline.  Never set in tests or bench.
     bool ablate_stride0 = false;
     bool transform_only = false;
+    bool use_als = false;
     bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     // profiling
@@ -204,6 +205,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->loss_type = cfg->loss_type;
     c->transform_only = (cfg->flags & ALPINE_FLAG_TRANSFORM_ONLY) != 0;
     c->bf16 = (cfg->flags & ALPINE_FLAG_X_BF16) != 0;
+    c->use_als = (cfg->flags & ALPINE_FLAG_USE_ALS) != 0;
     c->device = cfg->device_id;
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -652,48 +654,83 @@ static int grow_losses(alpine_ctx* c)
     return 0;
 }
 
-// phase 2 on a view: [loss row of the factors that produced the reduce block], W update, B updates, W^TW, W^TX sweep,
-// H update of the view's cells.  finalize: append a loss row (the reduce block must then describe the FULL shard).
-static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
+static int launch_w_update(alpine_ctx* c, const float* HHt, bool update, int k_lo, int k_hi, bool block_orth)
 {
-    int rc;
-    const int KP = c->KP, K = c->K;
+    const int KP = c->KP;
     const float l2 = (float)((1.0 - c->l1r) * c->alpha), l1 = (float)(c->l1r * c->alpha);
-    const int wblocks = c->ndot / 4;
-    const size_t m_bytes = sizeof(float) * KP * KP;
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_kernel<KT_>, dim3(wblocks), dim3(256), m_bytes, c->stream, c->W, c->red,
-                                           c->red + c->red_hht, c->dotpart, c->G, K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0));
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_kernel<KT_>, dim3(c->ndot / 4), dim3(256), sizeof(float) * KP * KP, c->stream, c->W, c->red,
+                                           HHt, c->dotpart, c->G, c->K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0, k_lo, k_hi,
+                                           block_orth ? 1 : 0));
     HIPCHK(c, hipGetLastError());
-    if (finalize) {
-        if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, c->red + c->red_hht,
-                           c->red + c->red_stats, c->meta, c->nstat, KP, c->lam_dev, c->loss_dev + c->loss_rows * (c->n_cov + 2));
-        HIPCHK(c, hipGetLastError());
-        c->loss_rows++;
-    }
-    if (!update) return 0;
+    return 0;
+}
 
-    if (c->n_cov > 0) {
-        hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
-                           c->red + c->red_hht, c->meta, KP, (float)c->eps);
-        HIPCHK(c, hipGetLastError());
-        c->bcur ^= 1;
-    }
-    if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
-    if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    if ((rc = launch_sweep(c, v.gB, v.Xgn, c->W, c->piecesB, 1))) return rc;
-    if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi, int only_cov)
+{
+    const int KP = c->KP, K = c->K;
     const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
-    if (c->h_update_valu) {           // reference implementation of the same update on the VALU (A/B and fallback)
+    if (c->h_update_valu && !c->use_als) {   // reference implementation of the same update on the VALU (A/B and fallback)
         const int hblocks = (int)((v.N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
                                                c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
     } else {
         const int hblocks = (int)((v.N + 127) / 128);
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
-                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
+                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov));
     }
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int launch_sweep_wtx(alpine_ctx* c, const CellView& v)
+{
+    int rc;
+    if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    if ((rc = launch_sweep(c, v.gB, v.Xgn, c->W, c->piecesB, 1))) return rc;
+    return prof_end(c, ALPINE_KERNEL_SWEEP_WTX);
+}
+
+// phase 2 on a view: [loss row of the factors that produced the reduce block], W update, B updates, W^TW, W^TX sweep,
+// H update of the view's cells.  finalize: append a loss row (the reduce block must then describe the FULL shard).
+static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
+{
+    int rc;
+    const int KP = c->KP, K = c->K;
+    const float* HHt = c->red + c->red_hht;
+    // MU: this launch also updates W; block-coordinate: dot partials only (the group loop below updates W)
+    if ((rc = launch_w_update(c, HHt, update && !c->use_als, 0, K, false))) return rc;
+    if (finalize) {
+        if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, HHt,
+                           c->red + c->red_stats, c->meta, c->nstat, KP, c->lam_dev, c->loss_dev + c->loss_rows * (c->n_cov + 2));
+        HIPCHK(c, hipGetLastError());
+        c->loss_rows++;
+    }
+    if (!update) return 0;
+
+    // every B_i depends only on its own old B_i and old H_i, so all of them can be updated up front in both branches
+    if (c->n_cov > 0) {
+        hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
+                           HHt, c->meta, KP, (float)c->eps);
+        HIPCHK(c, hipGetLastError());
+        c->bcur ^= 1;
+    }
+    if (!c->use_als) {
+        if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
+        if ((rc = launch_sweep_wtx(c, v))) return rc;
+        return launch_h_update(c, v, 0, K, -1);
+    }
+    // block-coordinate branch, main.py:525-588: groups in the order [cov_1 .. cov_C, unguided]
+    int k_lo = 0;
+    for (int grp = 0; grp <= c->n_cov; ++grp) {
+        const int k_hi = grp < c->n_cov ? k_lo + c->cov_k[grp] : K;
+        if (grp > 0 && (rc = launch_gram(c, v.H, v.Np, v.gramBlocksH, c->red + c->red_hht))) return rc;   // H H^T with groups < grp updated
+        if ((rc = launch_w_update(c, HHt, true, k_lo, k_hi, true))) return rc;
+        if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
+        if ((rc = launch_sweep_wtx(c, v))) return rc;
+        if ((rc = launch_h_update(c, v, k_lo, k_hi, grp))) return rc;
+        k_lo = k_hi;
+    }
     return 0;
 }
 

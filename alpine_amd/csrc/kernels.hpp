@@ -511,8 +511,10 @@ template <int KT>
 __global__ __launch_bounds__(256)
 void w_update_kernel(float* __restrict__ W, const float* __restrict__ XHt, const float* __restrict__ HHt,
                      double* __restrict__ dotpart, int G, int K, float orth, float l2, float l1, float eps,
-                     int do_update)
+                     int do_update, int k_lo, int k_hi, int block_orth)
 {
+    // MU branch: k_lo = 0, k_hi = K, block_orth = 0.  Block-coordinate branch (main.py:533-545): only the columns
+    // [k_lo, k_hi) of one component group are updated and the orthogonality penalty couples that group's columns only.
     constexpr int KP = 32 * KT;
     constexpr int NH = (KP + 63) / 64;
     extern __shared__ float M[];
@@ -521,7 +523,10 @@ void w_update_kernel(float* __restrict__ W, const float* __restrict__ XHt, const
         for (int idx = tid; idx < KP * KP; idx += 256) {
             const int kp = idx / KP, k = idx % KP;
             float v = 0.f;
-            if (kp < K && k < K) v = 2.f * HHt[idx] + (kp == k ? l2 : orth);
+            if (kp < K && k < K) {
+                const bool coupled = !block_orth || (kp >= k_lo && kp < k_hi);
+                v = 2.f * HHt[idx] + (kp == k ? l2 : (coupled ? orth : 0.f));
+            }
             M[idx] = v;
         }
         __syncthreads();
@@ -569,7 +574,7 @@ void w_update_kernel(float* __restrict__ W, const float* __restrict__ XHt, const
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
             const int k = lane + 64 * hh;
-            if (g0 + i < G && k < K) {
+            if (g0 + i < G && k >= k_lo && k < k_hi) {
                 const float d = fmaxf(den[i][hh] + l1, eps);
                 W[(int64_t)(g0 + i) * KP + k] = w[i][hh] * ((2.f * x[i][hh]) / d);
             }
@@ -692,8 +697,11 @@ template <int KT>
 __global__ __launch_bounds__(256)
 void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
                           const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
-                          CovMeta meta, int N, int64_t Np, int K, float eps, int nB)
+                          CovMeta meta, int N, int64_t Np, int K, float eps, int nB, int k_lo, int k_hi, int only_cov)
 {
+    // MU branch: k_lo = 0, k_hi = K, only_cov = -1.  Block-coordinate branch (main.py:564-588): only the rows
+    // [k_lo, k_hi) of one component group are updated; guided terms only for that group's covariate (only_cov),
+    // none for the unguided group (only_cov = n_cov).
     constexpr int KP = 32 * KT;
     constexpr int GT = KT < 2 ? KT : 2;            // k tiles that can hold guided columns (sum k_i <= 64)
     extern __shared__ float smem[];
@@ -757,6 +765,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
 #pragma unroll
         for (int q = 0; q < 4; ++q) { gnum[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; gden[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int i = 0; i < meta.n_cov; ++i) {
+        if (only_cov >= 0 && i != only_cov) continue;
         const int off = meta.off[i], ki = meta.k[i], Ci = meta.lev[i], bo = meta.boff[i];
         const float lam = (meta.loss_type == 0) ? meta.lam[i] : meta.lam2[i];
         for (int cl = 0; cl < Ci; ++cl) {
@@ -803,7 +812,8 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                 float den = acc[m][4 * q + e];
                 if (m < GT) { num = gnum[m < GT ? m : 0][q][e] + num; den = gden[m < GT ? m : 0][q][e] + den; }
                 const float v = hreg[m][q][e] * (num / fmaxf(den, eps));
-                o[e] = (k4 + e < K) ? v : 0.f;
+                const int k = k4 + e;
+                o[e] = (k >= k_lo && k < k_hi) ? v : hreg[m][q][e];        // outside the range: unchanged (pads stay 0)
             }
             *reinterpret_cast<f32x4*>(H + n * KP + k4) = o;
         }

@@ -143,8 +143,8 @@ class ALPINE:
         return self
 
     def _check_supported(self, n_sample: int) -> None:
-        if self.use_als:
-            raise NotImplementedError("use_als=True (block-coordinate branch, main.py:523-588) is not part of the accelerated path yet")
+        if self.use_als and self.shard_cells:
+            raise NotImplementedError("use_als=True is single-device (the group loop needs HH^T of all cells after every group)")
         if self.sampling_method not in ("random", "weighted"):
             raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
         if self._uses_batches(n_sample):
@@ -184,7 +184,8 @@ class ALPINE:
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
                   loss_type=self.loss_type, device_id=dev_index, x_dtype=self.x_dtype,
-                  batch_capacity=(min(self.batch_size, N_total) if self._uses_batches(N_total) else 0))
+                  batch_capacity=(min(self.batch_size, N_total) if self._uses_batches(N_total) else 0),
+                  use_als=self.use_als)
         block, stream = None, None
         if sharded:
             # The engine and the collective must share ONE explicit stream: the default stream's handle is 0, which

@@ -50,7 +50,12 @@ enum {
      * v_mfma_f32_32x32x16_bf16), accumulation and all factor updates stay float32.  X chunks must start at a cell
      * index that is a multiple of 8.  Halves the HBM traffic of the two sweeps; tolerance vs the float32 path is
      * reported by the tests. */
-    ALPINE_FLAG_X_BF16 = 2
+    ALPINE_FLAG_X_BF16 = 2,
+    /* use_als=True of the reference (main.py:55, :523-588): block-coordinate updates, one component group
+     * (covariate blocks first, unguided last) at a time: W_j (orthogonality within the block only), then H_j, with
+     * HH^T / W^TW refreshed between groups.  One XH^T sweep + (C+1) W^TX sweeps per iteration.  Single shard only
+     * (the group loop needs the up-to-date HH^T of ALL cells after every group). */
+    ALPINE_FLAG_USE_ALS = 4
 };
 enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
 

@@ -13,6 +13,7 @@ It restates, in torch-CPU float32 (the arithmetic the reference itself uses on
 * ``mu_step_faithful``  <- MU branch of ``ALPINE._fit``       alpine/main.py:589-663
                            (incl. the per-epoch randperm gather, main.py:502-521,
                            alpine/utils/sampling.py:6-16, :58-71)
+* ``als_step_faithful`` <- block-coordinate branch (use_als)   alpine/main.py:523-588
 * ``loss_row``          <- ``ALPINE._compute_loss``           alpine/main.py:726-753
 * ``scale_factors``     <- ``ALPINE._scale_matrices``         alpine/main.py:772-781
 * ``transform_faithful``<- loop of ``ALPINE._transform``      alpine/main.py:705-709
@@ -51,6 +52,7 @@ class OracleParams:
     loss_type: str = "kl-divergence"
     eps: float = 1e-6
     random_state: int = 42
+    use_als: bool = False
 
     @property
     def n_all_components(self) -> List[int]:
@@ -164,6 +166,58 @@ def mu_step_faithful(p: OracleParams, s: OracleState, perm: Optional[torch.Tenso
         s.H[:, perm] = Hb                                   # main.py:659-663
 
 
+def als_step_faithful(p: OracleParams, s: OracleState, perm: Optional[torch.Tensor]) -> None:
+    """The block-coordinate branch, main.py:523-588 (``use_als=True``): for every component group j in the order
+    [cov_1 .. cov_C, unguided]: W_j (orthogonality mask of size k_j, main.py:537), then B_j (covariate groups), then H_j,
+    each against the CURRENT concatenated W and H (groups < j already updated in this pass)."""
+    eps = p.eps
+    offs, ks = p.offsets, p.n_all_components
+    n_cov = len(p.n_covariate_components)
+    if perm is None:
+        perm = torch.arange(s.X.shape[1])
+    Xb = s.X[:, perm]
+    Yb = [y[:, perm] for y in s.Ys]
+    for j in range(len(ks)):
+        a, b = offs[j], offs[j] + ks[j]
+        Hcat = s.H[:, perm]                                   # main.py:527-531 (re-gathered for every group)
+        Hj = Hcat[a:b]
+        W = s.W[:, a:b]
+        num = 2 * Xb @ Hj.T
+        den = (2 * s.W @ Hcat @ Hj.T + (1 - p.l1_ratio_W) * p.alpha_W * W @ torch.eye(ks[j], dtype=torch.float32)
+               + W @ orth_matrix(p, ks[j]))
+        den += p.l1_ratio_W * p.alpha_W * torch.ones_like(den)
+        den = torch.clamp(den, min=eps)
+        s.W = s.W.clone()
+        s.W[:, a:b] = W * (num / den)
+        if j < n_cov:                                          # main.py:548-562
+            Y, B = Yb[j], s.Bs[j]
+            if p.loss_type == "kl-divergence":
+                num = p.lam[j] * (Y / torch.clamp(B @ Hj, min=eps)) @ Hj.T
+                den = p.lam[j] * torch.ones_like(Y) @ Hj.T
+            else:
+                num = 2 * Y @ Hj.T
+                den = 2 * B @ Hj @ Hj.T
+            s.Bs[j] = B * (num / torch.clamp(den, min=eps))
+        Wj = s.W[:, a:b]                                       # main.py:565-588
+        unum = 2 * Wj.T @ Xb
+        uden = 2 * Wj.T @ (s.W @ Hcat)
+        if j < n_cov:
+            Y, B = Yb[j], s.Bs[j]
+            if p.loss_type == "kl-divergence":
+                gnum = p.lam[j] * B.T @ (Y / torch.clamp(B @ Hj, min=eps))
+                gden = p.lam[j] * B.T @ torch.ones_like(Y)
+            else:
+                gnum = 2 * p.lam[j] * B.T @ Y
+                gden = 2 * p.lam[j] * B.T @ (B @ Hj)
+            newH = Hj * ((unum + gnum) / torch.clamp(uden + gden, min=eps))
+        else:
+            newH = Hj * (unum / torch.clamp(uden, min=eps))
+        Hfull = s.H[a:b].clone()
+        Hfull[:, perm] = newH
+        s.H = s.H.clone()
+        s.H[a:b] = Hfull
+
+
 def loss_row(p: OracleParams, s: OracleState) -> List[float]:
     """main.py:726-753: [total, recon, pred_1..pred_C] as Python floats."""
     eps = p.eps
@@ -192,7 +246,7 @@ def fit_faithful(p: OracleParams, s: OracleState, max_iter: int, use_perm: bool 
         N = s.X.shape[1]
         for _ in range(max_iter):
             perm = torch.randperm(N) if use_perm else None
-            mu_step_faithful(p, s, perm)
+            (als_step_faithful if p.use_als else mu_step_faithful)(p, s, perm)
             if with_loss:
                 s.losses.append(loss_row(p, s))
     return s
@@ -218,7 +272,7 @@ def fit_faithful_batches(p: OracleParams, s: OracleState, max_iter: int, batch_s
         for _ in range(max_iter):
             epoch = torch.multinomial(w, N, True) if w is not None else torch.randperm(N)
             for b0 in range(0, N, bs):
-                mu_step_faithful(p, s, epoch[b0:min(b0 + bs, N)])
+                (als_step_faithful if p.use_als else mu_step_faithful)(p, s, epoch[b0:min(b0 + bs, N)])
             if with_loss:
                 s.losses.append(loss_row(p, s))
     return s

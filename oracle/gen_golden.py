@@ -126,6 +126,16 @@ CASES = [
     dict(name="full_weighted", n_cells=96, n_genes=64, seed=12, T=10, fit_kwargs=dict(sampling_method="weighted"),
          covariates=[("cond", ["a", "b", "c"], 0.0)],
          params=dict(n_components=4, n_covariate_components=[2], lam=[10.0], loss_type="frobenius")),
+    # block-coordinate branch (use_als=True, main.py:523-588)
+    dict(name="als_kl", n_cells=96, n_genes=64, seed=13, T=20,
+         covariates=[("cond", ["a", "b"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[1e3], use_als=True, orth_W=0.1, alpha_W=0.5, l1_ratio_W=0.3)),
+    dict(name="als_fro_2cov", n_cells=120, n_genes=80, seed=14, T=15,
+         covariates=[("c1", ["x", "y", "z"], 0.1), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=5, n_covariate_components=[2, 3], lam=[5.0, 2.0], loss_type="frobenius", use_als=True)),
+    dict(name="als_k74_mb", n_cells=300, n_genes=150, seed=15, T=6, fit_kwargs=dict(batch_size=128),
+         covariates=[("cond", ["a", "b", "c"], 0.0)],
+         params=dict(n_components=70, n_covariate_components=[4], lam=[1e3], use_als=True, orth_W=0.05)),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,

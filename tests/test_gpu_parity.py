@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import ALL_CASES, BATCH_CASES, SMALL_CASES, assert_loss_rows_close, load_case, rel_fro
+from _golden import ALL_CASES, ALS_CASES, BATCH_CASES, SMALL_CASES, assert_loss_rows_close, load_case, rel_fro
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ def make_engine(c, **kw):
         n_genes=c.X.shape[1], n_cells=c.X.shape[0], n_components=p["n_components"],
         cov_components=p["n_covariate_components"], cov_levels=[y.shape[0] for y in c.Ys], lam=p["lam"],
         orth_W=p.get("orth_W", 0.0), alpha_W=p.get("alpha_W", 0.0), l1_ratio_W=p.get("l1_ratio_W", 0.0),
-        eps=p.get("eps", 1e-6), loss_type=p.get("loss_type", "kl-divergence"), **kw)
+        eps=p.get("eps", 1e-6), loss_type=p.get("loss_type", "kl-divergence"), use_als=p.get("use_als", False), **kw)
     eng.upload_X_host(c.X)
     eng.finalize_X()
     for i, y in enumerate(c.Ys):
@@ -442,3 +442,30 @@ def test_batch_step_argument_errors():
     with pytest.raises(nat.AlpineNativeError):
         eng.batch_step(np.arange(4))
     eng.close()
+
+
+# ------------------------------------------------------------------ block-coordinate branch, use_als=True (next #3)
+@pytest.mark.parametrize("name", ALS_CASES)
+def test_als_drop_in_vs_reference(name):
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case(name)
+    adata = MiniAnnData(c.X.copy(), c.obs.copy())
+    model = ALPINE(device="cuda", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+    W = np.concatenate(model.matrices["Ws"], axis=1)
+    H = np.concatenate(model.matrices["Hs"], axis=0)
+    assert rel_fro(W, c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
+    for b, bt in zip(model.matrices["Bs"], c.BT):
+        assert rel_fro(b, bt) < 2e-4
+    assert_loss_rows_close(model.loss_history.to_numpy(), c.loss_history, n_cells=c.X.shape[0])
+
+
+@pytest.mark.parametrize("name", ["als_kl", "als_fro_2cov"])
+def test_als_single_step_vs_reference(name):
+    c = load_case(name)
+    eng = make_engine(c)
+    eng.run(1, with_loss=False)
+    W, H, Bs = eng.get_factors()
+    eng.close()
+    assert rel_fro(W, c.W1) < 1e-5 and rel_fro(H, c.H1) < 1e-5
+    for b, b1 in zip(Bs, c.B1):
+        assert rel_fro(b, b1) < 1e-5

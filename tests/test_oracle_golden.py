@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import ALL_CASES, BATCH_CASES, SMALL_CASES, assert_loss_rows_close, load_case, rel_fro
+from _golden import ALL_CASES, ALS_CASES, BATCH_CASES, SMALL_CASES, assert_loss_rows_close, load_case, rel_fro
 from oracle import alpine_oracle as orc
 
 
@@ -120,6 +120,20 @@ def test_minibatch_oracle_reproduces_reference(name):
     p = _params(c)
     s = _state(c, p)
     assert np.array_equal(s.W.numpy(), c.W0) and np.array_equal(s.H.numpy(), c.H0)
+    orc.fit_faithful_batches(p, s, c.T, c.fit_kwargs.get("batch_size"), c.fit_kwargs.get("sampling_method", "random"))
+    assert rel_fro(s.W.numpy(), c.WT_unscaled) < 2e-5
+    assert rel_fro(s.H.numpy(), c.HT_unscaled) < 2e-5
+    for b, bt in zip(s.Bs, c.BT_unscaled):
+        assert rel_fro(b.numpy(), bt) < 5e-5
+    np.testing.assert_allclose(np.array(s.losses), c.loss_history, rtol=5e-5)
+
+
+@pytest.mark.parametrize("name", ALS_CASES)
+def test_als_oracle_reproduces_reference(name):
+    c = load_case(name)
+    p = _params(c)
+    assert p.use_als
+    s = _state(c, p)
     orc.fit_faithful_batches(p, s, c.T, c.fit_kwargs.get("batch_size"), c.fit_kwargs.get("sampling_method", "random"))
     assert rel_fro(s.W.numpy(), c.WT_unscaled) < 2e-5
     assert rel_fro(s.H.numpy(), c.HT_unscaled) < 2e-5
