@@ -1,0 +1,71 @@
+"""Kneedle elbow detection for the ``max_iter=None`` warm-up of ``ALPINE.fit`` (alpine/main.py:116-129, :755-770).
+
+The reference delegates to the third-party package ``kneed`` (pinned ``kneed>=0.8.5,<0.9`` in its pyproject.toml:18),
+calling ``KneeLocator(x, log10(recon loss), curve="convex", direction="decreasing", interp_method="polynomial",
+polynomial_degree=2).elbow`` (main.py:758-765).  ``kneed`` is not vendored in the reference and is not installed in
+this image, so ``ALPINE._compute_best_iter`` uses the real package whenever it is importable and otherwise this
+restatement of the published algorithm (Satopaa, Albrecht, Irwin, Raghavan: "Finding a 'Kneedle' in a Haystack",
+ICDCS-W 2011) in the form kneed 0.8 implements it (offline mode, sensitivity S = 1):
+
+  1. smooth: least-squares polynomial of the given degree through (x, y);
+  2. normalise x and the smoothed y to [0, 1];
+  3. turn the (convex, decreasing) elbow into a knee: y <- max(y) - y;
+  4. difference curve d = y - x; its local maxima (>=) are knee candidates, local minima (<=) reset the threshold;
+  5. threshold of a candidate = d(candidate) - S * mean(|dx|);
+  6. walk the curve from the first candidate; the first point where d drops below the current threshold confirms
+     the candidate -> elbow = x[candidate].
+
+PARITY UNPINNED: neither the reference's tests (it has none) nor anything runnable here (kneed is absent, nothing may
+be installed) pins the elbow index this returns against kneed's; tests cover its invariants only.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+
+def _local_extrema(d: np.ndarray, greater: bool) -> np.ndarray:
+    """Indices i (interior) with d[i] >= both neighbours (or <=): scipy.signal.argrelextrema(d, np.greater_equal)
+    with order 1 and mode 'clip' also reports boundary points that tie with their single neighbour's clipped copy."""
+    n = len(d)
+    left = np.concatenate(([d[0]], d[:-1]))
+    right = np.concatenate((d[1:], [d[-1]]))
+    mask = (d >= left) & (d >= right) if greater else (d <= left) & (d <= right)
+    return np.flatnonzero(mask)
+
+
+def find_elbow(x, y, S: float = 1.0, polynomial_degree: int = 2) -> Optional[float]:
+    """Elbow of a convex, decreasing curve; returns the x value or None if no knee is found."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if len(x) < 3 or not np.all(np.isfinite(y)):
+        return None
+    ds_y = np.poly1d(np.polyfit(x, y, polynomial_degree))(x)
+    span_x, span_y = x.max() - x.min(), ds_y.max() - ds_y.min()
+    if span_x == 0 or span_y == 0:
+        return None
+    xn = (x - x.min()) / span_x
+    yn = (ds_y - ds_y.min()) / span_y
+    yn = yn.max() - yn                                  # convex + decreasing -> knee form
+    d = yn - xn
+    maxima = _local_extrema(d, greater=True)
+    minima = _local_extrema(d, greater=False)
+    if maxima.size == 0:
+        return None
+    tmx = d[maxima] - S * np.abs(np.diff(xn).mean())
+    threshold, threshold_index, mi = 0.0, int(maxima[0]), 0
+    is_max = np.zeros(len(d), dtype=bool); is_max[maxima] = True
+    is_min = np.zeros(len(d), dtype=bool); is_min[minima] = True
+    for i in range(int(maxima[0]), len(d)):
+        if xn[i] == 1.0:
+            break
+        if is_max[i]:
+            threshold = tmx[mi]
+            threshold_index = i
+            mi += 1
+        if is_min[i]:
+            threshold = 0.0
+        if d[i + 1] < threshold:
+            return float(x[threshold_index])
+    return None

@@ -348,16 +348,21 @@ class ALPINE:
 
     # -------------------------------------------------- warm-up elbow (main.py:755-770)
     def _compute_best_iter(self, train_loss) -> int:
+        """main.py:755-770: Kneedle elbow of log10(reconstruction loss) over the warm-up iterations.  Uses the real
+        ``kneed.KneeLocator`` (the reference's dependency) when importable, otherwise ``alpine_amd.kneedle`` (a
+        restatement of the published algorithm; parity with kneed unpinned, see that module)."""
+        import warnings
+        x = np.arange(0, len(train_loss))
+        y = np.log10(train_loss)
         try:
             from kneed import KneeLocator
-        except ImportError as e:  # the reference cannot even be imported without kneed
-            raise ImportError("fit(max_iter=None) needs the 'kneed' package for the Kneedle elbow (main.py:758); "
-                              "pass max_iter explicitly") from e
-        import warnings
-        kneedle = KneeLocator(np.arange(0, len(train_loss)), np.log10(train_loss), curve="convex",
-                              direction="decreasing", interp_method="polynomial", polynomial_degree=2)
-        if kneedle.elbow is not None:
-            return int(kneedle.elbow)
+            elbow = KneeLocator(x, y, curve="convex", direction="decreasing", interp_method="polynomial",
+                                polynomial_degree=2).elbow
+        except ImportError:
+            from .kneedle import find_elbow
+            elbow = find_elbow(x, y, S=1.0, polynomial_degree=2)
+        if elbow is not None:
+            return int(elbow)
         warnings.warn("Kneedle elbow not found, using default max_iter=200")
         return 200
 

@@ -469,3 +469,16 @@ def test_als_single_step_vs_reference(name):
     assert rel_fro(W, c.W1) < 1e-5 and rel_fro(H, c.H1) < 1e-5
     for b, b1 in zip(Bs, c.B1):
         assert rel_fro(b, b1) < 1e-5
+
+
+def test_fit_without_max_iter_runs_warmup_and_elbow():
+    """fit(max_iter=None), main.py:116-129: 200-iteration warm-up on the HIP path, elbow -> max_iter, then the real run."""
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case("kl_1cov")
+    adata = MiniAnnData(c.X.copy(), c.obs.copy())
+    model = ALPINE(device="cuda", **c.params).fit(adata, covariate_keys=c.keys)
+    assert isinstance(model.max_iter, int) and 1 <= model.max_iter <= 200
+    assert len(model.loss_history) == model.max_iter
+    # the final run restarts from the same seeded init: its first rows equal the reference's (which ran 50 iterations)
+    n = min(model.max_iter, c.T)
+    assert_loss_rows_close(model.loss_history.to_numpy()[:n], c.loss_history[:n], n_cells=c.X.shape[0])

@@ -192,3 +192,15 @@ def test_synthetic_generator_is_count_like():
     assert np.array_equal(X, synth_counts_host(300, 200, rank=8, seed=1))
     lab = synth_labels_host(50, ["a", "b"])
     assert lab.dtype.kind == "O" and set(lab) <= {"a", "b"}
+
+
+def test_kneedle_restatement_invariants():
+    """alpine_amd.kneedle (fallback for the absent `kneed`, parity unpinned): invariants of the published algorithm."""
+    from alpine_amd.kneedle import find_elbow
+    t = np.arange(200)
+    y = np.log10(1e6 * (0.3 + np.exp(-t / 15.0)))
+    e = find_elbow(t, y)
+    assert e is not None and 0 < e < 199 and float(e).is_integer()
+    assert find_elbow(t, 3.0 * y + 7.0) == e                    # affine changes of y do not move the elbow
+    assert find_elbow(10.0 * t + 5.0, y) == 10.0 * e + 5.0      # nor do affine changes of x (returned in x units)
+    assert find_elbow(t[:2], y[:2]) is None
