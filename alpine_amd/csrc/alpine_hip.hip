@@ -194,6 +194,13 @@ static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced)
     return g;
 }
 
+static int gram_rows_per_wave(int64_t R, int n_cu)
+{
+    // enough blocks to occupy the chip for small matrices (W: 20k rows), at most GR_ROWS_PER_WAVE rows per wave
+    int64_t rpw = round_up(std::max<int64_t>(16, R / (4 * (int64_t)n_cu)), 16);
+    return (int)std::min<int64_t>(GR_ROWS_PER_WAVE, rpw);
+}
+
 // ---------------------------------------------------------------------------------- create
 static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& g)
 {
@@ -264,7 +271,10 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     const int rows_per_gram_block = 4 * GR_ROWS_PER_WAVE;
     c->gramBlocksH = (int)((Np + rows_per_gram_block - 1) / rows_per_gram_block);
     c->gramBlocksW = (int)((Gp + rows_per_gram_block - 1) / rows_per_gram_block);
-    ALLOC(c, c->gramPart, float, (int64_t)std::max(c->gramBlocksH, c->gramBlocksW) * KP * KP);
+    {
+        auto nblk = [&](int64_t R) { const int rpw = gram_rows_per_wave(R, c->n_cu); return (R + 4 * rpw - 1) / (4 * rpw); };
+        ALLOC(c, c->gramPart, float, (int64_t)std::max(nblk(Np), nblk(Gp)) * KP * KP);
+    }
     c->statBlocks = (int)((c->N + HS_CELLS - 1) / HS_CELLS);
     ALLOC(c, c->statPart, float, (int64_t)c->statBlocks * std::max(1, c->nstat));
     ALLOC(c, c->kind, int, kind.size());
@@ -559,9 +569,11 @@ static int prof_end(alpine_ctx* c, int which)
     return 0;
 }
 
-static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int blocks, float* out)
+static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int /*blocks_hint*/, float* out)
 {
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(gram_kernel<KT_>, dim3(blocks), dim3(256), 0, c->stream, A, c->gramPart, (int)R));
+    const int rpw = gram_rows_per_wave(R, c->n_cu);
+    const int blocks = (int)((R + 4 * rpw - 1) / (4 * rpw));
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(gram_kernel<KT_>, dim3(blocks), dim3(256), 0, c->stream, A, c->gramPart, (int)R, rpw));
     HIPCHK(c, hipGetLastError());
     const int n = c->KP * c->KP;
     hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, out, n, blocks);
@@ -658,9 +670,17 @@ static int launch_w_update(alpine_ctx* c, const float* HHt, bool update, int k_l
 {
     const int KP = c->KP;
     const float l2 = (float)((1.0 - c->l1r) * c->alpha), l1 = (float)(c->l1r * c->alpha);
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_kernel<KT_>, dim3(c->ndot / 4), dim3(256), sizeof(float) * KP * KP, c->stream, c->W, c->red,
-                                           HHt, c->dotpart, c->G, c->K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0, k_lo, k_hi,
-                                           block_orth ? 1 : 0));
+    // dotpart has one float64 partial per wave of the VALU form (8 genes per wave); the MFMA form fills fewer
+    if (c->h_update_valu) {
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_kernel<KT_>, dim3(c->ndot / 4), dim3(256), sizeof(float) * KP * KP, c->stream, c->W, c->red,
+                                               HHt, c->dotpart, c->G, c->K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0, k_lo, k_hi,
+                                               block_orth ? 1 : 0));
+    } else {
+        // 32 genes per wave: ceil(G/128) blocks; the remaining dotpart entries stay at their initial zero
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_mfma_kernel<KT_>, dim3((c->G + 127) / 128), dim3(256), sizeof(float) * KP * KP, c->stream, c->W, c->red,
+                                               HHt, c->dotpart, c->G, c->K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0, k_lo, k_hi,
+                                               block_orth ? 1 : 0));
+    }
     HIPCHK(c, hipGetLastError());
     return 0;
 }

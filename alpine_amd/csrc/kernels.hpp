@@ -291,18 +291,18 @@ void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ 
 // gram: part[b][k][k'] = sum_{r in rows of block b} A[r][k] * A[r][k']     (A: R x KP, row-major)
 // Used for HH^T (A = H) and W^TW (A = W).  Each wave owns a contiguous row range; A and B MFMA
 // operands are the same registers.
-constexpr int GR_ROWS_PER_WAVE = 256;
+constexpr int GR_ROWS_PER_WAVE = 256;      // upper bound; small matrices use fewer rows per wave to fill the chip
 
 template <int KT>
 __global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
-void gram_kernel(const float* __restrict__ A, float* __restrict__ part, int R)
+void gram_kernel(const float* __restrict__ A, float* __restrict__ part, int R, int rows_per_wave)
 {
     constexpr int KP = 32 * KT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int gw = blockIdx.x * 4 + wave;
-    const int r0 = gw * GR_ROWS_PER_WAVE;
-    const int r1 = min(R, r0 + GR_ROWS_PER_WAVE);      // R is a multiple of 16
+    const int r0 = gw * rows_per_wave;
+    const int r1 = min(R, r0 + rows_per_wave);         // R and rows_per_wave are multiples of 16
 
     f32x16 acc[KT][KT];
 #pragma unroll
@@ -684,6 +684,44 @@ void h_update_kernel(float* __restrict__ H, const float* __restrict__ pieces, Sw
     }
 }
 
+// Sum of the pieces of tile ft for the k a lane owns in the MFMA C/D layout (k = 32m + 8q + 4h + e), row fl of the tile.
+// Ascending workgroup order, float64 accumulation; all 4*KT float4 loads of one piece are issued together so that a tile
+// with many pieces (small problems on the fixed stream-K grid) costs one memory latency per piece, not one per load.
+template <int KT>
+__device__ __forceinline__ void sg_sum_pieces(const float* __restrict__ pieces, const SweepGeom& g, int ft, int fl, int w_lo, int w_hi,
+                                              int h, bool valid, f32x4 (&out)[KT][4])
+{
+    constexpr int KP = 32 * KT;
+    double acc[KT][4][4];
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][q][e] = 0.0;
+    if (valid) {
+        for (int w = w_lo; w <= w_hi; ++w) {
+            const float* base = pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl * KP + 4 * h;
+            f32x4 v[KT][4];
+#pragma unroll
+            for (int m = 0; m < KT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[m][q] = *reinterpret_cast<const f32x4*>(base + 32 * m + 8 * q);
+#pragma unroll
+            for (int m = 0; m < KT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[m][q][e] += (double)v[m][q][e];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            out[m][q] = f32x4{(float)acc[m][q][0], (float)acc[m][q][1], (float)acc[m][q][2], (float)acc[m][q][3]};
+}
+
 // ----------------------------------------------------------------------------------------------
 // h_update on MFMA: one wave = 32 cells, lane (c, h) = cell n0+c, k-half h.
 //   den[k][cell] = sum_k' (2 W^TW)[k][k'] * H[cell][k']  as  D = A*B  with  A[k][k'] = M2 (symmetric, read transposed
@@ -723,23 +761,12 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     sg_tile_pieces(g, ft, w_lo, w_hi);
 
     f32x4 hreg[KT][4], xreg[KT][4];
+    sg_sum_pieces<KT>(pieces, g, ft, fl, w_lo, w_hi, h, valid, xreg);
 #pragma unroll
     for (int m = 0; m < KT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k4 = 32 * m + 8 * q + 4 * h;
-            f32x4 hv = {0.f, 0.f, 0.f, 0.f};
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            if (valid) {
-                hv = *reinterpret_cast<const f32x4*>(H + n * KP + k4);
-                for (int w = w_lo; w <= w_hi; ++w) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl * KP + k4);
-                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-                }
-            }
-            hreg[m][q] = hv;
-            xreg[m][q] = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
-        }
+        for (int q = 0; q < 4; ++q)
+            hreg[m][q] = valid ? *reinterpret_cast<const f32x4*>(H + n * KP + 32 * m + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x16 acc[KT];
 #pragma unroll
@@ -820,6 +847,88 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
 }
 
 // ----------------------------------------------------------------------------------------------
+// w_update on MFMA, same register trick as h_update_mfma_kernel with genes in place of cells:
+//   den[k][gene] = sum_k' M[k'][k] * W[gene][k'],   M = 2 HH^T + orth * (coupled off-diagonal) + l2 * I  (LDS, [k'][k])
+//   W[gene][k]  *= (2 XH^T[gene][k]) / max(den + l1, eps)   for k in [k_lo, k_hi)              main.py:596-605 / :533-545
+// plus the float64 partial of <XH^T, W_old> over the wave's 32 genes (trace-form loss), dotpart[wave].
+template <int KT>
+__global__ __launch_bounds__(256)
+void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, const float* __restrict__ HHt,
+                          double* __restrict__ dotpart, int G, int K, float orth, float l2, float l1, float eps,
+                          int do_update, int k_lo, int k_hi, int block_orth)
+{
+    constexpr int KP = 32 * KT;
+    extern __shared__ float Ml[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    if (do_update) {
+        for (int idx = tid; idx < KP * KP; idx += 256) {
+            const int kp = idx / KP, k = idx % KP;
+            float v = 0.f;
+            if (kp < K && k < K) {
+                const bool coupled = !block_orth || (kp >= k_lo && kp < k_hi);
+                v = 2.f * HHt[idx] + (kp == k ? l2 : (coupled ? orth : 0.f));
+            }
+            Ml[idx] = v;
+        }
+        __syncthreads();
+    }
+    const int gw = blockIdx.x * 4 + wave;
+    const int64_t g = (int64_t)gw * 32 + c;
+    const bool valid = g < G;
+    f32x4 wreg[KT][4], xreg[KT][4];
+    double dacc = 0.0;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = 32 * m + 8 * q + 4 * h;
+            wreg[m][q] = valid ? *reinterpret_cast<const f32x4*>(W + g * KP + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xreg[m][q] = valid ? *reinterpret_cast<const f32x4*>(XHt + g * KP + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dacc += (double)xreg[m][q][e] * (double)wreg[m][q][e];
+        }
+    dacc = wave_sum_f64(dacc);
+    if (lane == 0) dotpart[gw] = dacc;
+    if (!do_update) return;
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int mo = 0; mo < KT; ++mo)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mo][e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* mrow = Ml + (32 * m + 8 * q + 4 * h + e) * KP + c;      // A[i = k][kk = k'] = M[k'][k]
+#pragma unroll
+                for (int mo = 0; mo < KT; ++mo)
+                    acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], wreg[m][q][e], acc[mo], 0, 0, 0);
+            }
+    if (!valid) return;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = 32 * m + 8 * q + 4 * h;
+            if (k4 >= k_hi || k4 + 4 <= k_lo) continue;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k4 + e;
+                const float d = fmaxf(acc[m][4 * q + e] + l1, eps);
+                const float v = wreg[m][q][e] * ((2.f * xreg[m][q][e]) / d);
+                o[e] = (k >= k_lo && k < k_hi) ? v : wreg[m][q][e];
+            }
+            *reinterpret_cast<f32x4*>(W + g * KP + k4) = o;
+        }
+}
+
+// ----------------------------------------------------------------------------------------------
 // transform (alpine/main.py:705-709): n_iter times  H *= (2 W^T X) / max((2 W^T W) H, eps)  with W frozen.
 // The numerator is loop-invariant (one W^TX sweep) and every cell is independent, so all iterations of a
 // 32-cell tile run in registers: the updated H in the MFMA C/D layout is directly the next iteration's B operand
@@ -846,22 +955,13 @@ void h_iterate_mfma_kernel(float* __restrict__ H, const float* __restrict__ piec
     sg_tile_pieces(g, ft, w_lo, w_hi);
 
     f32x4 hreg[KT][4], num[KT][4];
+    sg_sum_pieces<KT>(pieces, g, ft, fl, w_lo, w_hi, h, valid, num);
 #pragma unroll
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k4 = 32 * m + 8 * q + 4 * h;
-            f32x4 hv = {0.f, 0.f, 0.f, 0.f};
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            if (valid) {
-                hv = *reinterpret_cast<const f32x4*>(H + n * KP + k4);
-                for (int w = w_lo; w <= w_hi; ++w) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl * KP + k4);
-                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-                }
-            }
-            hreg[m][q] = hv;
-            num[m][q] = f32x4{2.f * (float)a0, 2.f * (float)a1, 2.f * (float)a2, 2.f * (float)a3};
+            hreg[m][q] = valid ? *reinterpret_cast<const f32x4*>(H + n * KP + 32 * m + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+            num[m][q] = 2.f * num[m][q];
         }
 
     for (int it = 0; it < n_iter; ++it) {

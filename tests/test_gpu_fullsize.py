@@ -118,3 +118,62 @@ def test_frobenius_objective_non_increasing(big):
     total = eng.losses()[:, 0]
     assert (np.diff(total) <= 1e-6 * total[:-1]).all(), total
     eng.close()
+
+
+def test_metric_shape_cfg3_checksum_and_loss():
+    """BASELINE's metric shape itself (20 000 x 200 000, K = 50 + [5, 5]): exact XH^T checksum on integer counts,
+    trace-form loss == direct float64 loss, for both the float32 and the bf16 storage path (counts are bf16-exact)."""
+    from alpine_amd import _native
+    from alpine_amd.datasets import synth_counts_device_chunks
+    from alpine_amd.model import draw_initial_factors
+    dev = torch.device("cuda", 0)
+    Gc, Nc, ku, kc = 20000, 200000, 50, [5, 5]
+    K = ku + sum(kc)
+    W0, H0, B0 = draw_initial_factors(42, 1e-6, Gc, Nc, kc + [ku], [2, 2])
+    rng = np.random.default_rng(1)
+    Ys = []
+    for i in range(2):
+        lab = rng.integers(0, 2, size=Nc)
+        Y = np.zeros((2, Nc), dtype=np.float32)
+        Y[lab, np.arange(Nc)] = 1.0
+        Ys.append(Y)
+    results = {}
+    for dt in ("f32", "bf16"):
+        eng = _native.NativeShard(n_genes=Gc, n_cells=Nc, n_components=ku, cov_components=kc, cov_levels=[2, 2], lam=[1e3, 1e3],
+                                  alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5, x_dtype=dt)
+        rowsum = torch.zeros(Gc, dtype=torch.float64, device=dev)
+        xmax = 0.0
+        for off, chunk in synth_counts_device_chunks(Nc, Gc, rank=ku, seed=0, device=dev, chunk_cells=8192):
+            torch.cuda.synchronize()
+            eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
+            eng.synchronize()
+            rowsum.add_(chunk.sum(dim=0, dtype=torch.float64))
+            xmax = max(xmax, float(chunk.max()))
+            del chunk
+        assert xmax <= 256                      # small integer counts: exactly representable in bf16 as well
+        eng.finalize_X()
+        for i in range(2):
+            eng.upload_Y(i, Ys[i])
+        info = eng.info()
+        KP = info.k_padded
+        eng.set_factors(np.ones((Gc, K), np.float32), np.ones((K, Nc), np.float32), [np.full((2, 5), 0.5, np.float32)] * 2)
+        eng.iter_begin()
+        XHt = eng.read_buffer(_native.BUF_REDUCE_BLOCK, 0, info.genes_padded * KP).reshape(info.genes_padded, KP)
+        rs = rowsum.cpu().numpy()
+        assert rs.max() < 2 ** 24
+        assert np.array_equal(XHt[:Gc, :K].astype(np.float64), np.repeat(rs[:, None], K, axis=1)), dt
+        eng.set_factors(W0, H0, B0)
+        eng.run(4, with_loss=True)
+        losses = eng.losses()
+        W, H, _ = eng.get_factors()
+        assert np.isfinite(losses).all() and (W >= 0).all() and (H >= 0).all()
+        if dt == "f32":
+            direct = eng.eval_recon_direct()
+            assert abs(losses[-1, 1] - direct) <= 2e-5 * direct
+        results[dt] = (losses, W, H)
+        eng.close()
+        torch.cuda.empty_cache()
+    lf, lb = results["f32"][0], results["bf16"][0]
+    assert np.max(np.abs(lb[:, 1] - lf[:, 1]) / lf[:, 1]) < 1e-3            # bf16 operands: loss rows within 1e-3
+    from _golden import rel_fro
+    assert rel_fro(results["bf16"][2], results["f32"][2]) < 2e-2
