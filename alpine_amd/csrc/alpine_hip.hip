@@ -44,7 +44,11 @@ struct alpine_ctx {
     float *Xgn = nullptr, *Xng = nullptr, *W = nullptr, *H = nullptr, *Y = nullptr, *B[2] = {nullptr, nullptr};
     int bcur = 0;
     unsigned short *Xgn16 = nullptr, *Xng16 = nullptr, *Wp16 = nullptr, *Hp16 = nullptr;   // bf16 path (k-packed)
-    bool bf16 = false;
+    bool bf16 = false;                // any bf16-pipe mode (rounded operands or exact split)
+    bool split = false;               // exact-split mode
+    int npx = 1, npp = 1;             // bf16 planes of X / of the panels
+    int64_t x_plane = 0;              // elements between the planes of an X copy
+    int* xflags = nullptr;            // device: [0] some element of X not exact in the stored planes, [1] second plane in use
     float *piecesA = nullptr, *piecesB = nullptr;     // stream-K partial results of the two sweeps
     SweepGeom geomA{}, geomB{};
     CellView full{};                                  // the whole shard
@@ -211,7 +215,10 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->orth = cfg->orth_W; c->alpha = cfg->alpha_W; c->l1r = cfg->l1_ratio_W; c->eps = cfg->eps;
     c->loss_type = cfg->loss_type;
     c->transform_only = (cfg->flags & ALPINE_FLAG_TRANSFORM_ONLY) != 0;
-    c->bf16 = (cfg->flags & ALPINE_FLAG_X_BF16) != 0;
+    c->split = (cfg->flags & ALPINE_FLAG_X_SPLIT) != 0;
+    c->bf16 = (cfg->flags & ALPINE_FLAG_X_BF16) != 0 || c->split;
+    c->npx = c->split ? 2 : 1;        // two planes until alpine_finalize_X knows whether the second is needed
+    c->npp = c->split ? 3 : 1;
     c->use_als = (cfg->flags & ALPINE_FLAG_USE_ALS) != 0;
     c->device = cfg->device_id;
     HIPCHK(c, hipSetDevice(c->device));
@@ -252,10 +259,12 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->Xgn, float, c->bf16 ? 4 : Gp * Np);
     ALLOC(c, c->Xng, float, (c->transform_only || c->bf16) ? 4 : Np * Gp);
     if (c->bf16) {
-        ALLOC(c, c->Xgn16, unsigned short, Gp * Np);
-        ALLOC(c, c->Xng16, unsigned short, c->transform_only ? 8 : Np * Gp);
-        ALLOC(c, c->Wp16, unsigned short, Gp * KP);
-        ALLOC(c, c->Hp16, unsigned short, Np * KP);
+        c->x_plane = Gp * Np;
+        ALLOC(c, c->Xgn16, unsigned short, c->npx * Gp * Np);
+        ALLOC(c, c->Xng16, unsigned short, c->transform_only ? 8 : c->npx * Np * Gp);
+        ALLOC(c, c->Wp16, unsigned short, c->npp * Gp * KP);
+        ALLOC(c, c->Hp16, unsigned short, c->npp * Np * KP);
+        ALLOC(c, c->xflags, int, 4);
     }
     ALLOC(c, c->W, float, Gp * KP);
     ALLOC(c, c->H, float, Np * KP);
@@ -327,7 +336,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtW, c->Xgn16, c->Xng16, c->Wp16, c->Hp16, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtW, c->Xgn16, c->Xng16, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -351,11 +360,16 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
 }
 
 // ---------------------------------------------------------------------------------- ingest
+// planes == 0: round to one bf16 plane; planes >= 1: exact split into `planes` planes (plane_stride elements apart)
 static int launch_pack(alpine_ctx* c, const float* src, int64_t ld, int rows, int cols, unsigned short* dst, int64_t dst_cols,
-                       int64_t k0, int64_t f0, int rows_are_k)
+                       int64_t k0, int64_t f0, int rows_are_k, int planes = 0, int64_t plane_stride = 0, int* flags = nullptr)
 {
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
-    hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, c->stream, src, ld, rows, cols, dst, dst_cols, k0, f0, rows_are_k);
+    if (planes > 0)
+        hipLaunchKernelGGL(pack_split_kernel, grid, dim3(256), 0, c->stream, src, ld, rows, cols, dst, plane_stride, planes, dst_cols, k0, f0,
+                           rows_are_k, flags);
+    else
+        hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, c->stream, src, ld, rows, cols, dst, dst_cols, k0, f0, rows_are_k);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -366,12 +380,13 @@ static int upload_x_dev(alpine_ctx* c, const float* dev, int layout, int64_t ld,
     if (c->bf16) {
         if (cell0 % 8) return fail(c, ALPINE_ERR_BAD_ARG, "bf16 path: X chunks must start at a multiple of 8 cells (got %lld)", (long long)cell0);
         int rc;
+        const int pl = c->split ? 2 : 0;
         if (layout == ALPINE_X_CELLS_BY_GENES) {            // chunk[cell][gene]
-            if (!c->transform_only && (rc = launch_pack(c, dev, ld, (int)n, G, c->Xng16, c->Gp, cell0, 0, 1))) return rc;   // k = cell
-            if ((rc = launch_pack(c, dev, ld, (int)n, G, c->Xgn16, c->Np, 0, cell0, 0))) return rc;                          // k = gene
+            if (!c->transform_only && (rc = launch_pack(c, dev, ld, (int)n, G, c->Xng16, c->Gp, cell0, 0, 1, pl, c->x_plane, nullptr))) return rc;   // k = cell
+            if ((rc = launch_pack(c, dev, ld, (int)n, G, c->Xgn16, c->Np, 0, cell0, 0, pl, c->x_plane, c->xflags))) return rc;                        // k = gene
         } else {                                            // chunk[gene][cell]
-            if ((rc = launch_pack(c, dev, ld, G, (int)n, c->Xgn16, c->Np, 0, cell0, 1))) return rc;                          // k = gene
-            if (!c->transform_only && (rc = launch_pack(c, dev, ld, G, (int)n, c->Xng16, c->Gp, cell0, 0, 0))) return rc;   // k = cell
+            if ((rc = launch_pack(c, dev, ld, G, (int)n, c->Xgn16, c->Np, 0, cell0, 1, pl, c->x_plane, c->xflags))) return rc;                        // k = gene
+            if (!c->transform_only && (rc = launch_pack(c, dev, ld, G, (int)n, c->Xng16, c->Gp, cell0, 0, 0, pl, c->x_plane, nullptr))) return rc;   // k = cell
         }
         return 0;
     }
@@ -464,7 +479,15 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t n4 = c->Gp * c->Np / (c->bf16 ? 8 : 4);
     const int blocks = (int)std::min<int64_t>(4096, (n4 + 255) / 256);
-    if (c->bf16) hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn16, n4, c->f64part);
+    if (c->split) {
+        int h[2] = {0, 0};
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(h, c->xflags, sizeof h, hipMemcpyDeviceToHost));
+        if (h[0]) return fail(c, ALPINE_ERR_UNSUPPORTED, "X is not exactly representable as the sum of two bf16 planes (more than 16 significant bits): use the float32 layout");
+        c->npx = h[1] ? 2 : 1;        // small integer counts: the second plane is all zero and is never read
+    }
+    if (c->bf16) hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn16,
+                                    (c->split && c->npx == 2) ? c->Xgn16 + c->x_plane : (const unsigned short*)nullptr, n4, c->f64part);
     else hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn, n4, c->f64part);
     HIPCHK(c, hipGetLastError());
     int rc = sum_f64_partials(c, blocks, &c->xnorm2);
@@ -583,23 +606,30 @@ static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int /*blocks_hi
 
 // the two streaming sweeps share one launcher; the variant only changes the pipeline shape, never the result
 // which: 0 = XH^T (S = cells x genes copy, panel H), 1 = W^TX (S = genes x cells copy, panel W)
-static int launch_sweep_bf16(alpine_ctx* c, int which)
+static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g)
 {
-    const SweepGeom& g = which == 0 ? c->geomA : c->geomB;
     const float* master = which == 0 ? c->H : c->W;
     unsigned short* panel = which == 0 ? c->Hp16 : c->Wp16;
-    int rc = launch_pack(c, master, c->KP, g.R, c->KP, panel, c->KP, 0, 0, 1);      // float32 master -> k-packed bf16 operand copy
+    const int64_t p_plane = (int64_t)g.R * c->KP;
+    // float32 master -> k-packed bf16 operand copy (rounded, or three exact planes)
+    int rc = launch_pack(c, master, c->KP, g.R, c->KP, panel, c->KP, 0, 0, 1, c->split ? 3 : 0, p_plane, nullptr);
     if (rc) return rc;
     const unsigned short* S = which == 0 ? c->Xng16 : c->Xgn16;
     float* pieces = which == 0 ? c->piecesA : c->piecesB;
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(stream_gemm_bf16_kernel<KT_>, dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, panel, pieces, g));
+#define BF_LAUNCH(NPX, NPP) \
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, c->x_plane, \
+                                           panel, p_plane, pieces, g))
+    if (!c->split) { BF_LAUNCH(1, 1); }
+    else if (c->npx == 1) { BF_LAUNCH(1, 3); }
+    else { BF_LAUNCH(2, 3); }
+#undef BF_LAUNCH
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
 static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which)
 {
-    if (c->bf16) return launch_sweep_bf16(c, which);
+    if (c->bf16) return launch_sweep_bf16(c, which, g);
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
 #define SG_LAUNCH(RING, PASSES) \
     DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_kernel<KT_, RING, PASSES>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, P, pieces, ldS, g, (unsigned long long*)nullptr))

@@ -62,17 +62,21 @@ void pack_bf16_kernel(const float* __restrict__ src, int64_t ld_src, int rows, i
     }
 }
 
-// sum of squares of a k-packed bf16 array (n8 granules of 8) in float64
+// sum of squares of a k-packed bf16 array (n8 granules of 8; optional second plane x2 added element-wise) in float64
 __global__ __launch_bounds__(256)
-void sqnorm_bf16_kernel(const unsigned short* __restrict__ x, int64_t n8, double* __restrict__ part)
+void sqnorm_bf16_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int64_t n8,
+                        double* __restrict__ part)
 {
     __shared__ double red[256];
     double a = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+        u32x4 v2 = {0u, 0u, 0u, 0u};
+        if (x2) v2 = reinterpret_cast<const u32x4*>(x2)[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+            const float lo = __uint_as_float(v[j] << 16) + __uint_as_float(v2[j] << 16);
+            const float hi = __uint_as_float(v[j] & 0xffff0000u) + __uint_as_float(v2[j] & 0xffff0000u);
             a += (double)lo * lo + (double)hi * hi;
         }
     }
@@ -85,56 +89,138 @@ void sqnorm_bf16_kernel(const unsigned short* __restrict__ x, int64_t n8, double
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-// ----------------------------------------------------------------------------------------------
-// stream_gemm, bf16 operands: out[f][k] = sum_r S[r][f] * P[r][k], same stream-K work division, pieces, and
-// wave tiling (4 waves x 128 f columns x all KP) as the float32 kernel.  One k-step = 16 rows = one MFMA depth;
-// per k-step a wave issues 4 loads of 1 KiB (one per 32-column tile) and 4*KT MFMAs.  Ring of BF_RING k-steps
-// (16 loads, 64 VGPRs, 16 KiB per wave in flight); one panel stage (64 rows) per ring pass, one barrier per stage.
-constexpr int BF_RING = 4;                 // k-steps per panel stage = prefetch distance
-constexpr int BF_ROWS = 16 * BF_RING;      // 64 rows per stage == SG_ROW_ALIGN
+// Exact bf16 planes of a float32 value: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  hi + mid + lo == x
+// for every finite float32 whose residuals stay normal (24 significand bits = 3 x 8); count-like data needs only hi
+// (integers < 256) or hi + mid (16 significant bits, integers < 65536).
+__device__ __forceinline__ void f32_split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo)
+{
+    hi = f32_to_bf16_bits(x);
+    const float r1 = x - __uint_as_float((unsigned)hi << 16);
+    mid = f32_to_bf16_bits(r1);
+    const float r2 = r1 - __uint_as_float((unsigned)mid << 16);
+    lo = f32_to_bf16_bits(r2);
+}
 
-template <int KT, bool LAST>
-__device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RING][4], const unsigned short* __restrict__ lrow,
-                                         const unsigned short* __restrict__ xnext, int64_t f_stride8)
+// k-packed split of a float32 source tile into `planes` bf16 planes (plane p at dst + p * plane_stride), same
+// geometry conventions as pack_bf16_kernel.  flags[0] |= 1 if some element is NOT exactly the sum of the stored planes,
+// flags[1] |= 1 if some element has a non-zero second plane (so that a one-plane X can drop it).
+__global__ __launch_bounds__(256)
+void pack_split_kernel(const float* __restrict__ src, int64_t ld_src, int rows, int cols, unsigned short* __restrict__ dst,
+                       int64_t plane_stride, int planes, int64_t dst_cols, int64_t k0, int64_t f0, int rows_are_k,
+                       int* __restrict__ flags)
+{
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    for (int i = t; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(int64_t)(r0 + r) * ld_src + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    int inexact = 0, has_mid = 0;
+    for (int i = t; i < 512; i += 256) {
+        const int kb = i >> 6, fi = i & 63;
+        int64_t k_abs, f_abs;
+        float v[8];
+        if (rows_are_k) {
+            if (c0 + fi >= cols || r0 + 8 * kb >= rows) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[8 * kb + j][fi];
+            k_abs = k0 + r0 + 8 * kb; f_abs = f0 + c0 + fi;
+        } else {
+            if (r0 + fi >= rows || c0 + 8 * kb >= cols) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[fi][8 * kb + j];
+            k_abs = k0 + c0 + 8 * kb; f_abs = f0 + r0 + fi;
+        }
+        unsigned short pl[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32_split3(v[j], pl[0][j], pl[1][j], pl[2][j]);
+            float sum = __uint_as_float((unsigned)pl[0][j] << 16);
+            if (planes > 1) sum += __uint_as_float((unsigned)pl[1][j] << 16);
+            if (planes > 2) sum += __uint_as_float((unsigned)pl[2][j] << 16);
+            inexact |= (sum != v[j]);
+            has_mid |= (pl[1][j] & 0x7fff) != 0;
+        }
+        for (int p = 0; p < planes; ++p) {
+            u32x4 o = {(unsigned)pl[p][0] | ((unsigned)pl[p][1] << 16), (unsigned)pl[p][2] | ((unsigned)pl[p][3] << 16),
+                       (unsigned)pl[p][4] | ((unsigned)pl[p][5] << 16), (unsigned)pl[p][6] | ((unsigned)pl[p][7] << 16)};
+            *reinterpret_cast<u32x4*>(dst + p * plane_stride + ((k_abs / 8) * dst_cols + f_abs) * 8) = o;
+        }
+    }
+    if (flags) {
+        if (inexact) atomicOr(&flags[0], 1);
+        if (has_mid) atomicOr(&flags[1], 1);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// stream_gemm on the bf16 matrix pipe: out[f][k] = sum_r S[r][f] * P[r][k] with S given as NPX bf16 planes and P as NPP
+// bf16 planes (all k-packed).  Products of planes whose magnitudes matter at float32 precision are accumulated into the
+// same float32 accumulators: term (xp, pp) is used iff xp + pp <= NPP - 1.
+//   NPX = 1, NPP = 1 : plain bf16 operands (BASELINE config 5): operands rounded to bf16
+//   NPX = 1, NPP = 3 : X exactly one bf16 plane (small integer counts), panel exact in 3 planes -> float32-grade result, 3 MFMAs
+//   NPX = 2, NPP = 3 : X exact in two planes (16 significant bits), 5 MFMAs
+// bf16 x bf16 products are exact in float32, so the split forms differ from the float32 MFMA path only in summation order.
+// Same stream-K work division, pieces and wave tiling (4 waves x 128 f columns x all KP) as the float32 kernel.  One
+// k-step = 16 rows = one v_mfma_f32_32x32x16_bf16 depth; per k-step and X plane a wave issues 4 loads of 1 KiB.  The
+// X ring holds BF_RING k-steps (16 KiB per wave in flight in every variant); one panel stage per ring pass.
+template <int KT, int NPX, int NPP, int BF_RING, bool LAST>
+__device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RING][NPX][4], const unsigned short* __restrict__ lrow,
+                                         const unsigned short* __restrict__ xnext, int64_t f_stride8, int64_t x_plane, int lds_plane)
 {
     constexpr int KP = 32 * KT;
+    constexpr int UNITS = BF_RING * NPP;               // (k-step, panel plane) units; A fragments are prefetched one unit ahead
     u32x4 a[2][KT];
 #pragma unroll
     for (int m = 0; m < KT; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(lrow + (32 * m) * 8);
 #pragma unroll
-    for (int p = 0; p < BF_RING; ++p) {
-        if (p + 1 < BF_RING) {
+    for (int u = 0; u < UNITS; ++u) {
+        const int p = u / NPP, pp = u % NPP;
+        if (u + 1 < UNITS) {
+            const int p1 = (u + 1) / NPP, pp1 = (u + 1) % NPP;
 #pragma unroll
             for (int m = 0; m < KT; ++m)
-                a[(p + 1) & 1][m] = *reinterpret_cast<const u32x4*>(lrow + ((2 * (p + 1)) * KP + 32 * m) * 8);
+                a[(u + 1) & 1][m] = *reinterpret_cast<const u32x4*>(lrow + pp1 * lds_plane + ((2 * p1) * KP + 32 * m) * 8);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < KT; ++m)
+        for (int xp = 0; xp < NPX; ++xp) {
+            if (xp + pp <= NPP - 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[p & 1][m]),
-                                                                    __builtin_bit_cast(bf16x8, x[p][j]), acc[m][j], 0, 0, 0);
-        if (!LAST) {
+                for (int m = 0; m < KT; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                x[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xnext + (2 * p) * f_stride8 + j * (32 * 8)));
+                    for (int j = 0; j < 4; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[u & 1][m]),
+                                                                            __builtin_bit_cast(bf16x8, x[p][xp][j]), acc[m][j], 0, 0, 0);
+            }
+        }
+        if (!LAST && pp == NPP - 1) {                  // last use of x[p][*]: refill the ring slot for the next stage
+#pragma unroll
+            for (int xp = 0; xp < NPX; ++xp)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xnext + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int KT>
+template <int KT, int NPX, int NPP>
 __global__ __launch_bounds__(SG_THREADS, (KT <= 2 ? 2 : 1))
-void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, const unsigned short* __restrict__ P,
-                             float* __restrict__ pieces, SweepGeom g)
+void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_plane, const unsigned short* __restrict__ P,
+                             int64_t p_plane, float* __restrict__ pieces, SweepGeom g)
 {
     constexpr int KP = 32 * KT;
-    constexpr int STAGE_BF16 = BF_ROWS * KP;                        // bf16 elements of one panel stage
-    constexpr int PV = STAGE_BF16 / 8 / SG_THREADS;                 // 16-byte granules per thread per stage (= KT)
-    static_assert(STAGE_BF16 / 8 % SG_THREADS == 0, "panel stage must tile the workgroup exactly");
-    static_assert(BF_ROWS == SG_ROW_ALIGN, "stream-K spans are multiples of one stage");
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2][STAGE_BF16];
+    constexpr int BF_RING = NPP == 1 ? 4 : 2;                       // k-steps in the X ring (rounded bf16: 16 loads in flight;
+                                                                    // split forms: 8 or 16 loads, 3-5x the MFMA work per load)
+    constexpr int BF_ROWS = 16 * BF_RING;                           // rows per panel stage
+    static_assert(SG_ROW_ALIGN % BF_ROWS == 0, "stream-K spans are multiples of one stage");
+    constexpr int STAGE_BF16 = BF_ROWS * KP;                        // bf16 elements of one panel stage, per plane
+    constexpr int GRAN = STAGE_BF16 / 8;                            // 16-byte granules per plane per stage
+    constexpr int PV = (NPP * GRAN + SG_THREADS - 1) / SG_THREADS;  // granules per thread per stage
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][NPP * STAGE_BF16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,7 +234,7 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, const unsigne
     const int64_t f_stride8 = (int64_t)g.F * 8;                     // bf16 elements between consecutive 8-row blocks of S
 
     u32x4 preg[PV];
-    u32x4 x[BF_RING][4];
+    u32x4 x[BF_RING][NPX][4];
 
     while (pos < pos_end) {
         const int ft = (int)(pos / g.R);
@@ -159,15 +245,23 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, const unsigne
         const int f0 = (ft * SG_WAVES + wave) * SG_WAVE_F;
         const bool active = f0 < g.F;
 
-        const unsigned short* pptr = P + (int64_t)(r_begin / 8) * KP * 8 + 8 * tid;
+        const unsigned short* pptr = P + (int64_t)(r_begin / 8) * KP * 8;
         auto load_p = [&](int t) {
-            const unsigned short* q = pptr + (int64_t)t * STAGE_BF16;
 #pragma unroll
-            for (int v = 0; v < PV; ++v) preg[v] = *reinterpret_cast<const u32x4*>(q + 8 * SG_THREADS * v);
+            for (int v = 0; v < PV; ++v) {
+                const int gi = tid + SG_THREADS * v;                // granule index over planes
+                if (NPP * GRAN % SG_THREADS == 0 || gi < NPP * GRAN) {
+                    const int pl = gi / GRAN, gq = gi % GRAN;
+                    preg[v] = *reinterpret_cast<const u32x4*>(pptr + pl * p_plane + (int64_t)t * STAGE_BF16 + 8 * gq);
+                }
+            }
         };
         auto store_p = [&](int b) {
 #pragma unroll
-            for (int v = 0; v < PV; ++v) *reinterpret_cast<u32x4*>(&lds[b][8 * (tid + SG_THREADS * v)]) = preg[v];
+            for (int v = 0; v < PV; ++v) {
+                const int gi = tid + SG_THREADS * v;
+                if (NPP * GRAN % SG_THREADS == 0 || gi < NPP * GRAN) *reinterpret_cast<u32x4*>(&lds[b][8 * gi]) = preg[v];
+            }
         };
 
         __syncthreads();
@@ -202,8 +296,10 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, const unsigne
 #pragma unroll
         for (int p = 0; p < BF_RING; ++p)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                x[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xrow + (2 * p) * f_stride8 + j * (32 * 8)));
+            for (int xp = 0; xp < NPX; ++xp)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xrow + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
 
@@ -212,17 +308,17 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, const unsigne
             store_p((t + 1) & 1);
             load_p(t + 2);
             __builtin_amdgcn_sched_barrier(0);
-            bf_stage<KT, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8);
+            bf_stage<KT, NPX, NPP, BF_RING, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
             __syncthreads();
         }
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            bf_stage<KT, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8);
+            bf_stage<KT, NPX, NPP, BF_RING, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
             __syncthreads();
             ++t;
         }
-        bf_stage<KT, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8);
+        bf_stage<KT, NPX, NPP, BF_RING, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = 128*wave + 32*j + c
         float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * SG_BLOCK_F + wave * SG_WAVE_F + c) * KP + 4 * h;

@@ -85,10 +85,13 @@ class ALPINE:
         # extension (not in the reference): shard the cell axis over the ranks of the default
         # torch.distributed process group, one process per GPU.  Default: single device.
         self.shard_cells = shard_cells
-        # extension: "bf16" stores X and the MFMA operand copies of W/H in bf16 (fp32 accumulation, fp32 master
-        # factors); default "f32" is the reference's arithmetic.
-        if x_dtype not in ("f32", "bf16"):
-            raise ValueError("x_dtype must be 'f32' or 'bf16'")
+        # extension: storage / matrix-pipe mode of the two sweeps.  "f32" (default) is the reference's arithmetic on the
+        # float32 MFMA.  "bf16" rounds X and the operand copies of W/H to bf16 (fp32 accumulation, fp32 masters).
+        # "split" keeps X as 1-2 bf16 planes that sum EXACTLY to the input and W/H operands as 3 exact planes: float32-grade
+        # results on the bf16 matrix pipe; raises if X is not exactly representable (more than 16 significant bits).
+        # "auto" = "split" when X allows it, else "f32".
+        if x_dtype not in ("f32", "bf16", "split", "auto"):
+            raise ValueError("x_dtype must be 'f32', 'bf16', 'split' or 'auto'")
         self.x_dtype = x_dtype
 
         self._validate_init_args()
@@ -150,8 +153,8 @@ class ALPINE:
         if self._uses_batches(n_sample):
             if self.shard_cells:
                 raise NotImplementedError("mini-batch / weighted sampling is single-device for now (no shard_cells)")
-            if self.x_dtype != "f32":
-                raise NotImplementedError("mini-batch / weighted sampling needs x_dtype='f32'")
+            if self.x_dtype not in ("f32", "auto"):
+                raise NotImplementedError("mini-batch / weighted sampling needs x_dtype='f32' (or 'auto')")
 
     def _uses_batches(self, n_sample: int) -> bool:
         """Full batch with the 'random' permutation is the in-place fast path (the permutation only re-orders sums);
@@ -180,10 +183,13 @@ class ALPINE:
         self._rng_post_init = torch.get_rng_state()
         self._rng_replay = (N_total, n_iter)
 
+        x_dtype = self.x_dtype
+        if x_dtype == "auto":
+            x_dtype = "f32" if self._uses_batches(N_total) else "split"
         kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
-                  loss_type=self.loss_type, device_id=dev_index, x_dtype=self.x_dtype,
+                  loss_type=self.loss_type, device_id=dev_index, x_dtype=x_dtype,
                   batch_capacity=(min(self.batch_size, N_total) if self._uses_batches(N_total) else 0),
                   use_als=self.use_als)
         block, stream = None, None
@@ -198,13 +204,29 @@ class ALPINE:
                 stream.synchronize()
                 kw.update(stream=stream.cuda_stream, reduce_block=block.data_ptr())
                 assert stream.cuda_stream != 0
-        eng = _native.NativeShard(**kw)
+        def make_engine(dtype):
+            e = _native.NativeShard(**{**kw, "x_dtype": dtype})
+            try:
+                chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)    # multiple of 8 cells (bf16 paths pack 8 rows per granule)
+                for r0 in range(c0, c1, chunk):
+                    r1 = min(c1, r0 + chunk)
+                    e.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r1], dtype=np.float32), _native.X_CELLS_BY_GENES, r0 - c0)
+                e.finalize_X()
+            except Exception:
+                e.close()
+                raise
+            return e
+
         try:
-            chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)        # multiple of 8 cells (bf16 path packs 8 rows per granule)
-            for r0 in range(c0, c1, chunk):
-                r1 = min(c1, r0 + chunk)
-                eng.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r1], dtype=np.float32), _native.X_CELLS_BY_GENES, r0 - c0)
-            eng.finalize_X()
+            eng = make_engine(x_dtype)
+        except _native.AlpineNativeError as err:
+            # "auto" only: X has more than 16 significant bits somewhere -> the exact split does not apply, use float32
+            if not (self.x_dtype == "auto" and x_dtype == "split" and err.code == -5):
+                raise
+            x_dtype = "f32"
+            eng = make_engine(x_dtype)
+        self.x_dtype_used = x_dtype
+        try:
             for i, y in enumerate(Y):
                 eng.upload_Y(i, np.ascontiguousarray(y[c0:c1].T))
             eng.set_factors(W0, H0, B0, h_col0=c0)
@@ -276,14 +298,27 @@ class ALPINE:
         # main.py:687-689: U[0,1) from the global generator, NOT reseeded, NOT clamped
         H0 = torch.rand((self.total_components, n_sample), dtype=torch.float32).numpy()
         W = np.ascontiguousarray(np.concatenate(self.matrices["Ws"], axis=1), dtype=np.float32)
-        eng = _native.NativeShard(n_genes=G, n_cells=n_sample, n_components=self.total_components, cov_components=[],
-                                  cov_levels=[], lam=[], eps=self.eps, device_id=dev_index, transform_only=True,
-                                  x_dtype=self.x_dtype)
+        def make_engine(dtype):
+            e = _native.NativeShard(n_genes=G, n_cells=n_sample, n_components=self.total_components, cov_components=[],
+                                    cov_levels=[], lam=[], eps=self.eps, device_id=dev_index, transform_only=True, x_dtype=dtype)
+            try:
+                chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)
+                for r0 in range(0, n_sample, chunk):
+                    e.upload_X_host(np.ascontiguousarray(X[r0:r0 + chunk], dtype=np.float32), _native.X_CELLS_BY_GENES, r0)
+                e.finalize_X()
+            except Exception:
+                e.close()
+                raise
+            return e
+
+        x_dtype = "split" if self.x_dtype == "auto" else self.x_dtype
         try:
-            chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)
-            for r0 in range(0, n_sample, chunk):
-                eng.upload_X_host(np.ascontiguousarray(X[r0:r0 + chunk], dtype=np.float32), _native.X_CELLS_BY_GENES, r0)
-            eng.finalize_X()
+            eng = make_engine(x_dtype)
+        except _native.AlpineNativeError as err:
+            if not (self.x_dtype == "auto" and err.code == -5):
+                raise
+            eng = make_engine("f32")
+        try:
             eng.set_factors(W, H0, [])
             eng.transform(n_iter)
             _, H, _ = eng.get_factors()

@@ -52,9 +52,12 @@ def parse_args():
     ap.add_argument("--cells", type=int, default=None, help="override the number of cells")
     ap.add_argument("--genes", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the extra (non-headline) split / bf16 measurements at N=1")
     ap.add_argument("--no-loss", action="store_true", help="updates only (secondary number)")
     ap.add_argument("--cpu-sample-cells", type=int, default=6000)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage type of X and the MFMA operands (accumulation is f32)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "split"],
+                    help="f32: float32 MFMA (reference arithmetic); bf16: operands rounded to bf16; split: exact bf16 planes of X and "
+                         "of the operands on the bf16 matrix pipe (float32-grade results; needs bf16-exact X such as counts)")
     ap.add_argument("--split-a", type=int, default=0)
     ap.add_argument("--split-b", type=int, default=0)
     return ap.parse_args()
@@ -175,86 +178,141 @@ def main():
     lam = [1e3] * len(kcov)
     levels = [2] * len(kcov)
 
-    kw = dict(n_genes=G, n_cells=n_loc, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
-              orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], eps=1e-6,
-              loss_type="kl-divergence", device_id=local_rank, split_a=args.split_a, split_b=args.split_b, x_dtype=args.dtype)
-    block, stream = None, None
+    with_loss = not args.no_loss
+    stream = None
     if world > 1:
         # engine kernels and the RCCL all-reduce share ONE explicit stream (the default stream's handle is 0, which the
         # C ABI reads as "create a private stream" -- that would leave the collective unordered with the kernels)
         stream = torch.cuda.Stream(dev)
         torch.cuda.set_stream(stream)
-        nfl = _native.reduce_block_floats(G, n_loc, ku, kcov, levels)
-        block = torch.zeros(nfl, dtype=torch.float32, device=dev)
-        stream.synchronize()
         assert stream.cuda_stream != 0
-        kw.update(stream=stream.cuda_stream, reduce_block=block.data_ptr())
-    eng = _native.NativeShard(**kw)
-
-    # ---- synthetic input, generated on the device in cell chunks (never on the host)
-    t_gen = time.perf_counter()
-    for off, chunk in synth_counts_device_chunks(n_loc, G, rank=ku, seed=0, device=dev, chunk_cells=8192, cell_offset=c0):
-        torch.cuda.synchronize()
-        eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
-        eng.synchronize()
-        del chunk
-    eng.finalize_X()
-    torch.cuda.empty_cache()
-    for i in range(len(kcov)):
-        eng.upload_Y(i, np.ascontiguousarray(labels_onehot(N, seed=1 + i)[:, c0:c1]))
     W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], levels)
-    eng.set_factors(W0, H0, B0, h_col0=c0)
-    t_gen = time.perf_counter() - t_gen
-    info = eng.info()
+    Ys = [np.ascontiguousarray(labels_onehot(N, seed=1 + i)[:, c0:c1]) for i in range(len(kcov))]
 
-    loop = ShardedLoop(eng, TorchDistComm(block)) if world > 1 else None
-    with_loss = not args.no_loss
-
-    def run(n):
-        if loop is not None:
-            loop.run(n, with_loss=with_loss)
-        else:
-            eng.run(n, with_loss=with_loss)
-
-    def fence():
-        eng.synchronize()
-        torch.cuda.synchronize()
+    def measure(dtype: str) -> dict:
+        """Build the resident state for one storage mode, run `warmup` untimed and `steps` timed iterations."""
+        kw = dict(n_genes=G, n_cells=n_loc, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
+                  orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], eps=1e-6,
+                  loss_type="kl-divergence", device_id=local_rank, split_a=args.split_a, split_b=args.split_b, x_dtype=dtype)
+        block = None
         if world > 1:
-            dist.barrier()
+            nfl = _native.reduce_block_floats(G, n_loc, ku, kcov, levels)
+            block = torch.zeros(nfl, dtype=torch.float32, device=dev)
+            stream.synchronize()
+            kw.update(stream=stream.cuda_stream, reduce_block=block.data_ptr())
+        eng = _native.NativeShard(**kw)
+        try:
+            # synthetic input, generated on the device in cell chunks (never on the host)
+            t_gen = time.perf_counter()
+            for off, chunk in synth_counts_device_chunks(n_loc, G, rank=ku, seed=0, device=dev, chunk_cells=8192, cell_offset=c0):
+                torch.cuda.synchronize()
+                eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
+                eng.synchronize()
+                del chunk
+            eng.finalize_X()
+            torch.cuda.empty_cache()
+            for i in range(len(kcov)):
+                eng.upload_Y(i, Ys[i])
+            eng.set_factors(W0, H0, B0, h_col0=c0)
+            t_gen = time.perf_counter() - t_gen
+            info = eng.info()
+            loop = ShardedLoop(eng, TorchDistComm(block)) if world > 1 else None
+
+            def run(n):
+                if loop is not None:
+                    loop.run(n, with_loss=with_loss)
+                else:
+                    eng.run(n, with_loss=with_loss)
+
+            def fence():
+                eng.synchronize()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                    torch.cuda.synchronize()
+
+            run(args.warmup)
+            fence()
+            eng.reset_losses()
+            eng.set_profiling(True)
+            t0 = time.perf_counter()
+            run(args.steps)
+            eng.synchronize()
             torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            fence()
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            ms_a, n_a = eng.kernel_time(_native.KERNEL_SWEEP_XHT)
+            ms_b, n_b = eng.kernel_time(_native.KERNEL_SWEEP_WTX)
+            losses = eng.losses()
+            eng.set_profiling(False)
+        finally:
+            eng.close()
+            del block
+            torch.cuda.empty_cache()
+        return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen)
 
-    run(args.warmup)
-    fence()
-    eng.reset_losses()
-    eng.set_profiling(True)
-    t0 = time.perf_counter()
-    run(args.steps)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    fence()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    DTYPE_LABEL = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate",
+                   "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)"}
 
-    ms_a, n_a = eng.kernel_time(_native.KERNEL_SWEEP_XHT)
-    ms_b, n_b = eng.kernel_time(_native.KERNEL_SWEEP_WTX)
-    losses = eng.losses()
-    eng.set_profiling(False)
+    def roofline(m: dict) -> dict:
+        dtype, info = m["dtype"], m["info"]
+        mf = dtype == "f32"
+        launches = m["n_a"] + m["n_b"]
+        avg_ms = (m["ms_a"] + m["ms_b"]) / max(1, launches)
+        flops_per_launch = 2.0 * G * n_loc * K                    # algorithmic, unpadded K (SURVEY.md 8d: 4GNK per iteration / 2 sweeps)
+        bytes_per_launch = (4.0 if mf else 2.0) * G * n_loc       # X read once per sweep (counts: ONE bf16 plane in split mode)
+        ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        tr = pmc_traffic(args.workload, world, info.k_padded, dtype) if not (args.cells or args.genes) else None
+        return {
+            "kernel": ("stream_gemm_kernel (MFMA f32 32x32x2; XH^T and W^TX sweeps)" if mf else
+                       "stream_gemm_bf16_kernel (MFMA bf16 32x32x16, k-packed X; XH^T and W^TX sweeps)" +
+                       (" with exact plane split" if dtype == "split" else "")),
+            "bound": "mfma" if mf else "hbm",
+            "achieved": ach_tf if mf else gbps,
+            "peak": FP32_MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBPS,
+            "unit": "TFLOP/s" if mf else "GB/s",
+            "frac": (ach_tf / FP32_MFMA_PEAK_TFLOPS) if mf else gbps / HBM_PEAK_GBPS,
+            "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
+            "avg_launch_ms": avg_ms, "launches": launches,
+            "avg_ms_xht": m["ms_a"] / max(1, m["n_a"]), "avg_ms_wtx": m["ms_b"] / max(1, m["n_b"]),
+            "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "tflops": ach_tf, "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS,
+            "sweeps_share_of_step": (m["ms_a"] + m["ms_b"]) / (1e3 * m["dt"]) if m["dt"] > 0 else 0.0,
+        }
+
+    main_m = measure(args.dtype)
+    others = {}
+    if world == 1 and not args.no_other_modes and not args.no_loss:
+        # the same workload in the other storage modes (not the headline): exact bf16-plane split (float32-grade
+        # results, applies because the synthetic counts are bf16-exact) and rounded bf16 operands (BASELINE config 5)
+        for dt_name in ("split", "bf16", "f32"):
+            if dt_name == args.dtype:
+                continue
+            try:
+                om = measure(dt_name)
+                others[dt_name] = {
+                    "dtype": DTYPE_LABEL[dt_name], "value": args.steps / om["dt"], "unit": "iterations/s",
+                    "ms_per_step": 1e3 * om["dt"] / args.steps, "roofline": roofline(om),
+                    "final_loss_row": om["losses"][-1].tolist() if len(om["losses"]) else None,
+                    "final_total_loss_rel_diff_vs_headline": (abs(om["losses"][-1][0] - main_m["losses"][-1][0]) / abs(main_m["losses"][-1][0])
+                                                              if len(om["losses"]) and len(main_m["losses"]) else None),
+                    "device_GiB": round(om["info"].device_bytes / 2**30, 2),
+                }
+            except Exception as e:            # an optional leg must not take the headline down
+                others[dt_name] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        it_s = args.steps / dt
-        launches = n_a + n_b
-        avg_ms = (ms_a + ms_b) / max(1, launches)
-        flops_per_launch = 2.0 * G * n_loc * K                    # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
-        bytes_per_launch = (4.0 if args.dtype == "f32" else 2.0) * G * n_loc      # X read once per sweep
-        ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        dt, info, losses = main_m["dt"], main_m["info"], main_m["losses"]
         out = {
             "metric": "NMF update iterations/sec (20k genes x 200k cells, K=50)",
-            "value": it_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": args.steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": args.dtype if args.dtype == "f32" else "bf16 operands, f32 accumulate", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_LABEL[args.dtype], "data": "synthetic",
             "config": {
                 "workload": (f"{args.workload}: {G} genes x {N} cells, K={ku}+{kcov} (K={K}), {len(kcov)} two-level covariates, "
                              f"lam=1e3, alpha_W={wl['alpha_W']}, orth_W={wl['orth_W']}, l1_ratio_W={wl['l1_ratio_W']}, KL loss, "
@@ -263,32 +321,16 @@ def main():
                 "grid_xht": info.grid_a, "grid_wtx": info.grid_b, "device_GiB": round(info.device_bytes / 2**30, 2),
                 "parallelism": f"cells/{world}",
             },
-            "roofline": (lambda mf: {
-                "kernel": ("stream_gemm_kernel (MFMA f32 32x32x2; XH^T and W^TX sweeps)" if mf else
-                           "stream_gemm_bf16_kernel (MFMA bf16 32x32x16, k-packed X; XH^T and W^TX sweeps)"),
-                "bound": "mfma" if mf else "hbm",
-                "achieved": ach_tf if mf else bytes_per_launch / (avg_ms * 1e-3) / 1e9,
-                "peak": FP32_MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBPS,
-                "unit": "TFLOP/s" if mf else "GB/s",
-                "frac": (ach_tf / FP32_MFMA_PEAK_TFLOPS) if mf else bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "traffic": (pmc_traffic(args.workload, world, info.k_padded, args.dtype) or {}).get("bytes_per_launch") if not (args.cells or args.genes) else None,
-                "traffic_detail": pmc_traffic(args.workload, world, info.k_padded, args.dtype) if not (args.cells or args.genes) else None,
-                "avg_launch_ms": avg_ms, "launches": launches,
-                "avg_ms_xht": ms_a / max(1, n_a), "avg_ms_wtx": ms_b / max(1, n_b),
-                "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "tflops": ach_tf, "hbm_achieved_GBps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                "hbm_frac_of_8TBps": bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if avg_ms > 0 else 0.0,
-                "sweeps_share_of_step": (ms_a + ms_b) / (1e3 * dt) if dt > 0 else 0.0,
-            })(args.dtype == "f32"),
+            "roofline": roofline(main_m),
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
-            "setup_s": t_gen,
+            "setup_s": main_m["t_gen"],
+            "other_modes": others or None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample_cells, N), N)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

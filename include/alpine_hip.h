@@ -55,7 +55,14 @@ enum {
      * (covariate blocks first, unguided last) at a time: W_j (orthogonality within the block only), then H_j, with
      * HH^T / W^TW refreshed between groups.  One XH^T sweep + (C+1) W^TX sweeps per iteration.  Single shard only
      * (the group loop needs the up-to-date HH^T of ALL cells after every group). */
-    ALPINE_FLAG_USE_ALS = 4
+    ALPINE_FLAG_USE_ALS = 4,
+    /* exact-split storage: X is kept as one or two bf16 planes whose sum is EXACTLY the float32 input (integer counts
+     * < 256 need one plane, 16 significant bits two), the MFMA operand copies of W / H as three bf16 planes that sum
+     * exactly to the float32 masters; the sweeps run on the bf16 matrix pipe (3 or 5 MFMAs per fragment pair), products
+     * are exact in float32 and accumulate in float32, so results agree with the float32 path to rounding -- at HBM-bound
+     * instead of fp32-MFMA-bound speed.  alpine_finalize_X fails with ALPINE_ERR_UNSUPPORTED if some element of X is not
+     * exactly representable by two bf16 planes (then use the float32 layout).  X chunks start at multiples of 8 cells. */
+    ALPINE_FLAG_X_SPLIT = 8
 };
 enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
 

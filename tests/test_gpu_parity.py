@@ -482,3 +482,77 @@ def test_fit_without_max_iter_runs_warmup_and_elbow():
     # the final run restarts from the same seeded init: its first rows equal the reference's (which ran 50 iterations)
     n = min(model.max_iter, c.T)
     assert_loss_rows_close(model.loss_history.to_numpy()[:n], c.loss_history[:n], n_cells=c.X.shape[0])
+
+
+# ------------------------------------------------------------------ exact-split storage on the bf16 matrix pipe
+def _count_like(c, scale):
+    """Integer-valued X from a golden case's matrix: scale=40 -> < 256 mostly? no: forces the range we want below."""
+    import copy
+    c2 = copy.copy(c)
+    c2.X = np.floor(c.X * scale).astype(np.float32)
+    return c2
+
+
+@pytest.mark.parametrize("name,scale,planes", [("kl_2cov_nan", 6.0, 1), ("ragged", 6.0, 1), ("kl_2cov_nan", 900.0, 2),
+                                               ("k105", 900.0, 2), ("counts_2cov", 1.0, 1)])
+def test_split_matches_fp32_path(name, scale, planes):
+    """x_dtype='split': X as 1 or 2 exact bf16 planes, W/H operands as 3 exact planes.  bf16 x bf16 products are exact in
+    float32, so the whole fit must agree with the float32-MFMA path to ROUNDING (1e-5 after a step, 1e-4 after the fit),
+    not to bf16 tolerance."""
+    c = _count_like(load_case(name), scale)
+    xmax = float(c.X.max())
+    assert (planes == 1) == (xmax < 256) and xmax < 65536
+    a = make_engine(c)
+    b = make_engine(c, x_dtype="split")
+    assert abs(a.info().x_sqnorm - b.info().x_sqnorm) <= 1e-12 * a.info().x_sqnorm
+    a.run(1, with_loss=False)
+    b.run(1, with_loss=False)
+    Wa, Ha, _ = a.get_factors()
+    Wb, Hb, _ = b.get_factors()
+    assert rel_fro(Wb, Wa) < 1e-5 and rel_fro(Hb, Ha) < 1e-5
+    a.run(c.T - 1, with_loss=True)
+    b.run(c.T - 1, with_loss=True)
+    Wa, Ha, Ba = a.get_factors()
+    Wb, Hb, Bb = b.get_factors()
+    assert rel_fro(Wb, Wa) < 1e-4 and rel_fro(Hb, Ha) < 1e-4
+    for x, y in zip(Bb, Ba):
+        assert rel_fro(x, y) < 2e-4
+    assert_loss_rows_close(b.losses(), a.losses(), n_cells=c.X.shape[0])
+    a.close()
+    b.close()
+
+
+def test_split_vs_reference_on_counts():
+    """The golden count case through the split path against the REFERENCE itself (float32 tolerances)."""
+    c = load_case("counts_2cov")
+    eng = make_engine(c, x_dtype="split")
+    eng.run(c.T, with_loss=True)
+    W, H, Bs = eng.get_factors()
+    assert rel_fro(W, c.WT_unscaled) < 1e-4 and rel_fro(H, c.HT_unscaled) < 1e-4
+    for b, bt in zip(Bs, c.BT_unscaled):
+        assert rel_fro(b, bt) < 2e-4
+    assert_loss_rows_close(eng.losses(), c.loss_history, n_cells=c.X.shape[0])
+    eng.close()
+
+
+def test_split_refuses_inexact_X_and_auto_falls_back():
+    nat = _native()
+    c = load_case("kl_1cov")                       # gamma-distributed float32: 24 significant bits
+    p = c.params
+    eng = nat.NativeShard(n_genes=c.X.shape[1], n_cells=c.X.shape[0], n_components=p["n_components"],
+                          cov_components=p["n_covariate_components"], cov_levels=[2], lam=p["lam"], x_dtype="split")
+    eng.upload_X_host(c.X)
+    with pytest.raises(nat.AlpineNativeError) as e:
+        eng.finalize_X()
+    assert e.value.code == -5
+    eng.close()
+    from alpine_amd import ALPINE, MiniAnnData
+    m = ALPINE(device="cuda", x_dtype="auto", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
+    assert m.x_dtype_used == "f32"
+    assert rel_fro(np.concatenate(m.matrices["Hs"], axis=0), c.HT) < 1e-4
+    with pytest.raises(nat.AlpineNativeError):
+        ALPINE(device="cuda", x_dtype="split", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=2)
+    cc = load_case("counts_2cov")
+    m = ALPINE(device="cuda", x_dtype="auto", **cc.params).fit(MiniAnnData(cc.X.copy(), cc.obs.copy()), covariate_keys=cc.keys, max_iter=cc.T)
+    assert m.x_dtype_used == "split"
+    assert rel_fro(np.concatenate(m.matrices["Hs"], axis=0), cc.HT) < 1e-4
