@@ -121,7 +121,7 @@ def pmc_traffic(workload: str, world: int, kp: int, dtype: str = "f32"):
         return None
     best = None
     import re
-    tag = "" if dtype == "f32" else "_bf16"
+    tag = {"f32": "", "bf16": "_bf16", "split": "_split"}[dtype]
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", f"{workload}{tag}_stream_gemm_pmc_summary.json"))):
         try:
             d = json.load(open(f))
