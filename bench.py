@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra (non-headline) split / bf16 measurements at N=1")
     ap.add_argument("--no-loss", action="store_true", help="updates only (secondary number)")
-    ap.add_argument("--cpu-sample-cells", type=int, default=6000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=12000)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "split"],
                     help="f32: float32 MFMA (reference arithmetic); bf16: operands rounded to bf16; split: exact bf16 planes of X and "
                          "of the operands on the bf16 matrix pipe (float32-grade results; needs bf16-exact X such as counts)")

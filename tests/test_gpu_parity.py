@@ -556,3 +556,22 @@ def test_split_refuses_inexact_X_and_auto_falls_back():
     m = ALPINE(device="cuda", x_dtype="auto", **cc.params).fit(MiniAnnData(cc.X.copy(), cc.obs.copy()), covariate_keys=cc.keys, max_iter=cc.T)
     assert m.x_dtype_used == "split"
     assert rel_fro(np.concatenate(m.matrices["Hs"], axis=0), cc.HT) < 1e-4
+
+
+def test_split_transform_matches_fp32_transform():
+    """alpine_transform through the exact-split path == through the float32 path (same W, same H0), to rounding."""
+    nat = _native()
+    c = load_case("counts_2cov")
+    K = c.WT.shape[1]
+    H0 = np.random.default_rng(3).random((K, c.X.shape[0]), dtype=np.float32)
+    outs = {}
+    for dt in ("f32", "split"):
+        eng = nat.NativeShard(n_genes=c.X.shape[1], n_cells=c.X.shape[0], n_components=K, cov_components=[], cov_levels=[], lam=[],
+                              transform_only=True, x_dtype=dt)
+        eng.upload_X_host(c.X)
+        eng.finalize_X()
+        eng.set_factors(c.WT, H0, [])
+        eng.transform(20)
+        outs[dt] = eng.get_factors()[1]
+        eng.close()
+    assert rel_fro(outs["split"], outs["f32"]) < 2e-5
