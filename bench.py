@@ -46,8 +46,8 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--cells", type=int, default=None, help="override the number of cells")
     ap.add_argument("--genes", type=int, default=None)
@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "split"],
                     help="f32: float32 MFMA (reference arithmetic); bf16: operands rounded to bf16; split: exact bf16 planes of X and "
                          "of the operands on the bf16 matrix pipe (float32-grade results; needs bf16-exact X such as counts)")
+    ap.add_argument("--x-scale", type=float, default=1.0, help="multiply the synthetic counts (e.g. 300 -> values need two bf16 planes)")
     ap.add_argument("--split-a", type=int, default=0)
     ap.add_argument("--split-b", type=int, default=0)
     return ap.parse_args()
@@ -205,6 +206,8 @@ def main():
             # synthetic input, generated on the device in cell chunks (never on the host)
             t_gen = time.perf_counter()
             for off, chunk in synth_counts_device_chunks(n_loc, G, rank=ku, seed=0, device=dev, chunk_cells=8192, cell_offset=c0):
+                if args.x_scale != 1.0:
+                    chunk = (chunk * args.x_scale).contiguous()
                 torch.cuda.synchronize()
                 eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
                 eng.synchronize()
