@@ -1,0 +1,123 @@
+"""Randomised shapes through the C ABI against the CPU oracle (fused form = the kernels' numerical spec): ragged G / N
+(not multiples of any tile), K from 1 to ~100, 0-2 covariates with 1-4 levels, both loss types, regularisers on/off,
+several stream-K span sizes, float32 and (on integer data) the exact-split path.  Two MU steps + loss rows each."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import rel_fro
+from oracle import alpine_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(seed)
+    G = int(rng.integers(3, 300))
+    N = int(rng.integers(3, 420))
+    n_cov = int(rng.integers(0, 3))
+    ks = [int(rng.integers(1, 7)) for _ in range(n_cov)]
+    levels = [int(rng.integers(1, 5)) for _ in range(n_cov)]
+    Ku = int(rng.choice([1, 2, 5, 17, 30, 33, 60, 64, 65, 90]))
+    Ku = min(Ku, 128 - sum(ks))
+    loss = ["kl-divergence", "frobenius"][int(rng.integers(0, 2))]
+    reg = bool(rng.integers(0, 2))
+    integer = bool(rng.integers(0, 2))
+    X = rng.gamma(0.5, 2.0, size=(N, G)).astype(np.float32)
+    if integer:
+        X = np.floor(X * (3 if rng.integers(0, 2) else 400)).astype(np.float32)
+    Ys = []
+    for C in levels:
+        lab = rng.integers(-1 if C > 1 else 0, C, size=N)          # -1 = missing label -> all-zero row
+        Y = np.zeros((N, C), dtype=np.float32)
+        ok = lab >= 0
+        Y[np.flatnonzero(ok), lab[ok]] = 1.0
+        Ys.append(Y)
+    p = orc.OracleParams(n_components=Ku, n_covariate_components=ks, lam=[float(rng.choice([1.0, 50.0, 1e3])) for _ in ks],
+                         orth_W=0.1 if reg else 0.0, alpha_W=0.7 if reg else 0.0, l1_ratio_W=0.4 if reg else 0.0,
+                         loss_type=loss, random_state=int(seed))
+    return p, X, Ys, integer, (int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_shape_two_steps_vs_oracle(seed):
+    from alpine_amd import _native as nat
+    p, X, Ys, integer, splits = _case(seed)
+    s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
+    W0, H0, B0 = s.W.numpy().copy(), s.H.numpy().copy(), [b.numpy().copy() for b in s.Bs]
+    orc.fit_fused(p, s, 2, with_loss=True)
+    modes = ["f32"] + (["split"] if integer and float(X.max()) < 65536 else [])
+    for mode in modes:
+        eng = nat.NativeShard(n_genes=X.shape[1], n_cells=X.shape[0], n_components=p.n_components,
+                              cov_components=p.n_covariate_components, cov_levels=[y.shape[1] for y in Ys], lam=p.lam,
+                              orth_W=p.orth_W, alpha_W=p.alpha_W, l1_ratio_W=p.l1_ratio_W, eps=p.eps, loss_type=p.loss_type,
+                              split_a=splits[0], split_b=splits[1], x_dtype=mode)
+        eng.upload_X_host(X)
+        eng.finalize_X()
+        for i, y in enumerate(Ys):
+            eng.upload_Y(i, np.ascontiguousarray(y.T))
+        eng.set_factors(W0, H0, B0)
+        eng.run(2, with_loss=True)
+        W, H, Bs = eng.get_factors()
+        losses = eng.losses()
+        eng.close()
+        tag = f"seed {seed} mode {mode} G={X.shape[1]} N={X.shape[0]} K={p.total_components} cov={p.n_covariate_components} {p.loss_type}"
+        assert np.isfinite(W).all() and np.isfinite(H).all(), tag
+        assert rel_fro(W, s.W.numpy()) < 2e-5, tag
+        assert rel_fro(H, s.H.numpy()) < 2e-5, tag
+        for b, bo in zip(Bs, s.Bs):
+            assert rel_fro(b, bo.numpy()) < 5e-5, tag
+        want = np.array(s.losses)
+        assert losses.shape == want.shape, tag
+        np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=1e-4, err_msg=tag)
+        np.testing.assert_allclose(losses[:, 2:], want[:, 2:], rtol=2e-3, atol=1e-6 * X.shape[0], err_msg=tag)
+
+
+@pytest.mark.parametrize("seed", list(range(100, 110)))
+def test_random_shape_als_and_minibatch_vs_oracle(seed):
+    """Block-coordinate branch (use_als) and mini-batch steps on random shapes against the oracle's op-for-op restatement
+    (als_step_faithful / mu_step_faithful on explicit index batches)."""
+    from alpine_amd import _native as nat
+    p, X, Ys, _, _ = _case(seed)
+    if not p.n_covariate_components:            # the reference's ALS / sampler code needs at least one covariate
+        p.n_covariate_components, p.lam = [2], [10.0]
+        Ys = [np.eye(2, dtype=np.float32)[np.random.default_rng(seed).integers(0, 2, size=X.shape[0])]]
+    use_als = seed % 2 == 0
+    p.use_als = use_als
+    N = X.shape[0]
+    rng = np.random.default_rng(seed + 7)
+    bs = int(rng.integers(max(2, N // 4), N + 1))
+    batches = []
+    for _ in range(2):                           # two epochs of explicit index batches, with replacement in the second
+        epoch = rng.permutation(N) if not batches else rng.integers(0, N, size=N)
+        batches.append([epoch[b0:b0 + bs] for b0 in range(0, N, bs)])
+    s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
+    W0, H0, B0 = s.W.numpy().copy(), s.H.numpy().copy(), [b.numpy().copy() for b in s.Bs]
+    step = orc.als_step_faithful if use_als else orc.mu_step_faithful
+    with torch.no_grad():
+        for epoch in batches:
+            for idx in epoch:
+                step(p, s, torch.tensor(idx, dtype=torch.long))
+            s.losses.append(orc.loss_row(p, s))
+    eng = nat.NativeShard(n_genes=X.shape[1], n_cells=N, n_components=p.n_components, cov_components=p.n_covariate_components,
+                          cov_levels=[y.shape[1] for y in Ys], lam=p.lam, orth_W=p.orth_W, alpha_W=p.alpha_W,
+                          l1_ratio_W=p.l1_ratio_W, eps=p.eps, loss_type=p.loss_type, use_als=use_als, batch_capacity=bs)
+    eng.upload_X_host(X)
+    eng.finalize_X()
+    for i, y in enumerate(Ys):
+        eng.upload_Y(i, np.ascontiguousarray(y.T))
+    eng.set_factors(W0, H0, B0)
+    for epoch in batches:
+        for idx in epoch:
+            eng.batch_step(idx)
+        eng.epoch_loss()
+    W, H, Bs = eng.get_factors()
+    losses = eng.losses()
+    eng.close()
+    tag = f"seed {seed} als={use_als} G={X.shape[1]} N={N} bs={bs} K={p.total_components} cov={p.n_covariate_components} {p.loss_type}"
+    assert rel_fro(W, s.W.numpy()) < 5e-5, tag
+    assert rel_fro(H, s.H.numpy()) < 5e-5, tag
+    for b, bo in zip(Bs, s.Bs):
+        assert rel_fro(b, bo.numpy()) < 1e-4, tag
+    want = np.array(s.losses)
+    np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=1e-4, err_msg=tag)
