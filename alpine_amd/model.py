@@ -235,6 +235,19 @@ class ALPINE:
             elif sharded:
                 with torch.cuda.device(dev_index), torch.cuda.stream(stream):
                     ShardedLoop(eng, TorchDistComm(block)).run(n_iter, with_loss=True)
+            elif self.verbose:
+                # main.py:490-494, :669-671: tqdm bar with the objective loss.  The loop runs asynchronously on the device,
+                # so the bar advances in chunks (one host sync per chunk instead of one per iteration).
+                from tqdm import tqdm
+                step = max(1, n_iter // 20)
+                with tqdm(total=n_iter, desc="Iteration", ncols=100) as pbar:
+                    done = 0
+                    while done < n_iter:
+                        k = min(step, n_iter - done)
+                        eng.run(k, with_loss=True)
+                        done += k
+                        pbar.set_postfix({"objective loss": float(eng.losses()[-1, 0])})
+                        pbar.update(k)
             else:
                 eng.run(n_iter, with_loss=True)
             if scale:

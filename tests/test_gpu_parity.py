@@ -575,3 +575,14 @@ def test_split_transform_matches_fp32_transform():
         outs[dt] = eng.get_factors()[1]
         eng.close()
     assert rel_fro(outs["split"], outs["f32"]) < 2e-5
+
+
+def test_verbose_progress_bar_does_not_change_results(capsys):
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case("kl_1cov")
+    quiet = ALPINE(device="cuda", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
+    loud = ALPINE(device="cuda", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T, verbose=True)
+    assert "Iteration" in capsys.readouterr().err
+    assert np.array_equal(loud.loss_history.to_numpy(), quiet.loss_history.to_numpy())
+    for a, b in zip(loud.matrices["Hs"], quiet.matrices["Hs"]):
+        assert np.array_equal(a, b)
