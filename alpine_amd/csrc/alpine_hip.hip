@@ -44,6 +44,8 @@ struct alpine_ctx {
     float *Xgn = nullptr, *Xng = nullptr, *W = nullptr, *H = nullptr, *Y = nullptr, *B[2] = {nullptr, nullptr};
     int bcur = 0;
     unsigned short *Xgn16 = nullptr, *Xng16 = nullptr, *Wp16 = nullptr, *Hp16 = nullptr;   // bf16 path (k-packed)
+    unsigned short *Xgn16b = nullptr, *Xng16b = nullptr;     // second exact plane of X (split mode; freed if all zero)
+    int64_t x_plane_gn = 0, x_plane_ng = 0;                  // element offsets plane 2 - plane 1 of the two copies
     bool bf16 = false;                // any bf16-pipe mode (rounded operands or exact split)
     bool split = false;               // exact-split mode
     int npx = 1, npp = 1;             // bf16 planes of X / of the panels
@@ -260,8 +262,14 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->Xng, float, (c->transform_only || c->bf16) ? 4 : Np * Gp);
     if (c->bf16) {
         c->x_plane = Gp * Np;
-        ALLOC(c, c->Xgn16, unsigned short, c->npx * Gp * Np);
-        ALLOC(c, c->Xng16, unsigned short, c->transform_only ? 8 : c->npx * Np * Gp);
+        ALLOC(c, c->Xgn16, unsigned short, Gp * Np);
+        ALLOC(c, c->Xng16, unsigned short, c->transform_only ? 8 : Np * Gp);
+        if (c->split) {                                      // second plane in its own allocation so that it can be dropped
+            ALLOC(c, c->Xgn16b, unsigned short, Gp * Np);
+            ALLOC(c, c->Xng16b, unsigned short, c->transform_only ? 8 : Np * Gp);
+            c->x_plane_gn = c->Xgn16b - c->Xgn16;
+            c->x_plane_ng = c->Xng16b - c->Xng16;
+        }
         ALLOC(c, c->Wp16, unsigned short, c->npp * Gp * KP);
         ALLOC(c, c->Hp16, unsigned short, c->npp * Np * KP);
         ALLOC(c, c->xflags, int, 4);
@@ -336,7 +344,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtW, c->Xgn16, c->Xng16, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtW, c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -382,11 +390,11 @@ static int upload_x_dev(alpine_ctx* c, const float* dev, int layout, int64_t ld,
         int rc;
         const int pl = c->split ? 2 : 0;
         if (layout == ALPINE_X_CELLS_BY_GENES) {            // chunk[cell][gene]
-            if (!c->transform_only && (rc = launch_pack(c, dev, ld, (int)n, G, c->Xng16, c->Gp, cell0, 0, 1, pl, c->x_plane, nullptr))) return rc;   // k = cell
-            if ((rc = launch_pack(c, dev, ld, (int)n, G, c->Xgn16, c->Np, 0, cell0, 0, pl, c->x_plane, c->xflags))) return rc;                        // k = gene
+            if (!c->transform_only && (rc = launch_pack(c, dev, ld, (int)n, G, c->Xng16, c->Gp, cell0, 0, 1, pl, c->x_plane_ng, nullptr))) return rc;   // k = cell
+            if ((rc = launch_pack(c, dev, ld, (int)n, G, c->Xgn16, c->Np, 0, cell0, 0, pl, c->x_plane_gn, c->xflags))) return rc;                        // k = gene
         } else {                                            // chunk[gene][cell]
-            if ((rc = launch_pack(c, dev, ld, G, (int)n, c->Xgn16, c->Np, 0, cell0, 1, pl, c->x_plane, c->xflags))) return rc;                        // k = gene
-            if (!c->transform_only && (rc = launch_pack(c, dev, ld, G, (int)n, c->Xng16, c->Gp, cell0, 0, 0, pl, c->x_plane, nullptr))) return rc;   // k = cell
+            if ((rc = launch_pack(c, dev, ld, G, (int)n, c->Xgn16, c->Np, 0, cell0, 1, pl, c->x_plane_gn, c->xflags))) return rc;                        // k = gene
+            if (!c->transform_only && (rc = launch_pack(c, dev, ld, G, (int)n, c->Xng16, c->Gp, cell0, 0, 0, pl, c->x_plane_ng, nullptr))) return rc;   // k = cell
         }
         return 0;
     }
@@ -485,9 +493,13 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         HIPCHK(c, hipMemcpy(h, c->xflags, sizeof h, hipMemcpyDeviceToHost));
         if (h[0]) return fail(c, ALPINE_ERR_UNSUPPORTED, "X is not exactly representable as the sum of two bf16 planes (more than 16 significant bits): use the float32 layout");
         c->npx = h[1] ? 2 : 1;        // small integer counts: the second plane is all zero and is never read
+        if (c->npx == 1) {            // ... so give its memory back
+            if (c->Xgn16b) { HIPCHK(c, hipFree(c->Xgn16b)); c->Xgn16b = nullptr; c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
+            if (c->Xng16b) { HIPCHK(c, hipFree(c->Xng16b)); c->Xng16b = nullptr; if (!c->transform_only) c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
+        }
     }
     if (c->bf16) hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn16,
-                                    (c->split && c->npx == 2) ? c->Xgn16 + c->x_plane : (const unsigned short*)nullptr, n4, c->f64part);
+                                    (c->split && c->npx == 2) ? c->Xgn16b : (const unsigned short*)nullptr, n4, c->f64part);
     else hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn, n4, c->f64part);
     HIPCHK(c, hipGetLastError());
     int rc = sum_f64_partials(c, blocks, &c->xnorm2);
@@ -617,7 +629,8 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g)
     const unsigned short* S = which == 0 ? c->Xng16 : c->Xgn16;
     float* pieces = which == 0 ? c->piecesA : c->piecesB;
 #define BF_LAUNCH(NPX, NPP) \
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, c->x_plane, \
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, \
+                                           (which == 0 ? c->x_plane_ng : c->x_plane_gn), \
                                            panel, p_plane, pieces, g))
     if (!c->split) { BF_LAUNCH(1, 1); }
     else if (c->npx == 1) { BF_LAUNCH(1, 3); }
