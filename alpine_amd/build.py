@@ -7,7 +7,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "alpine_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hpp"), os.path.join(os.path.dirname(HERE), "include", "alpine_hip.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))] + \
+       [os.path.join(os.path.dirname(HERE), "include", "alpine_hip.h")]
 LIB = os.path.join(HERE, "libalpine_hip.so")
 
 

@@ -59,6 +59,7 @@ struct alpine_ctx {
     float *Xb_gn = nullptr, *Xb_ng = nullptr, *Hb = nullptr, *Yb = nullptr;
     int* idx_dev = nullptr;
     int slots = 512;
+    int sweep_waves = 4;              // waves per sweep workgroup (8 for the bf16 sweeps with K <= 64)
     float* red = nullptr;
     bool own_red = false;
     int64_t red_floats = 0, red_hht = 0, red_stats = 0;
@@ -84,6 +85,7 @@ struct alpine_ctx {
     // timing-only ablation (env ALPINE_HIP_ABLATE_STRIDE0=1): the sweeps re-read row 0 of X (served from cache) -> wrong
     // results, prices the HBM stream against the MFMA pipeline.  Never set in tests or bench.
     bool ablate_stride0 = false;
+    bool ablate_panel = false;        // env ALPINE_HIP_ABLATE_PANEL=1: bf16 sweeps re-read panel stage 0 (timing only, wrong results)
     bool transform_only = false;
     bool use_als = false;
     bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
@@ -122,6 +124,7 @@ static int fail(alpine_ctx* c, int code, const char* fmt, ...)
     }
 
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static bool getenv_is(const char* name, char v) { const char* e = std::getenv(name); return e && e[0] == v; }
 
 static int dev_alloc(alpine_ctx* c, void** p, size_t bytes, bool zero = true)
 {
@@ -186,11 +189,11 @@ extern "C" int64_t alpine_reduce_block_floats(const alpine_config* cfg)
 // Stream-K geometry of a sweep (see SweepGeom in kernels.hpp): a fixed grid of `slots` workgroups (as many as the
 // chip holds at once), each an equal span of L rows of the (tile,row) space.  forced > 0 asks for about `forced`
 // pieces per tile instead (tests use it to exercise spans that do / do not cross tiles).
-static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced)
+static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced, int bf = SG_BLOCK_F)
 {
     SweepGeom g{};
-    g.F = (int)F; g.R = (int)R;
-    g.nft = (int)((F + SG_BLOCK_F - 1) / SG_BLOCK_F);
+    g.F = (int)F; g.R = (int)R; g.bf = bf;
+    g.nft = (int)((F + bf - 1) / bf);
     const int64_t total = (int64_t)g.nft * R;
     int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
     want = std::max<int64_t>(1, std::min<int64_t>(want, total / SG_ROW_ALIGN));
@@ -230,6 +233,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         return fail(c, ALPINE_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("ALPINE_HIP_ABLATE_STRIDE0")) c->ablate_stride0 = (e[0] == '1');
+    if (const char* e = std::getenv("ALPINE_HIP_ABLATE_PANEL")) c->ablate_panel = (e[0] == '1');
     if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
     if (const char* e = std::getenv("ALPINE_HIP_H_UPDATE")) c->h_update_valu = (std::strcmp(e, "valu") == 0);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
@@ -252,11 +256,13 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
 
     const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
     // sweeps
-    const int slots = c->n_cu * (c->KT <= 2 ? 2 : 1);
+    // bf16 sweeps with K <= 64: 8-wave workgroups (1024-column tiles, one per CU); everything else 4 waves x 512 columns
+    c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;
+    const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 ? 2 : 1);
     c->slots = slots;
     c->batch_cap = cfg->batch_capacity;
-    c->geomA = make_geom(Gp, Np, slots, cfg->split_a);       // XH^T: f = genes, r = cells
-    c->geomB = make_geom(Np, Gp, slots, cfg->split_b);       // W^TX: f = cells, r = genes
+    c->geomA = make_geom(Gp, Np, slots, cfg->split_a, c->sweep_waves * SG_WAVE_F);       // XH^T: f = genes, r = cells
+    c->geomB = make_geom(Np, Gp, slots, cfg->split_b, c->sweep_waves * SG_WAVE_F);       // W^TX: f = cells, r = genes
 
     ALLOC(c, c->Xgn, float, c->bf16 ? 4 : Gp * Np);
     ALLOC(c, c->Xng, float, (c->transform_only || c->bf16) ? 4 : Np * Gp);
@@ -279,8 +285,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
     ALLOC(c, c->B[0], float, std::max(1, c->nB));
     ALLOC(c, c->B[1], float, std::max(1, c->nB));
-    ALLOC(c, c->piecesA, float, c->transform_only ? 4 : (int64_t)c->geomA.nwg * c->geomA.maxp * SG_BLOCK_F * KP);
-    ALLOC(c, c->piecesB, float, (int64_t)c->geomB.nwg * c->geomB.maxp * SG_BLOCK_F * KP);
+    ALLOC(c, c->piecesA, float, c->transform_only ? 4 : (int64_t)c->geomA.nwg * c->geomA.maxp * c->geomA.bf * KP);
+    ALLOC(c, c->piecesB, float, (int64_t)c->geomB.nwg * c->geomB.maxp * c->geomB.bf * KP);
     c->red_floats = g.red_floats; c->red_hht = g.red_hht; c->red_stats = g.red_stats;
     if (cfg->reduce_block) { c->red = (float*)cfg->reduce_block; c->own_red = false; HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream)); }
     else { ALLOC(c, c->red, float, c->red_floats); c->own_red = true; }
@@ -618,24 +624,34 @@ static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int /*blocks_hi
 
 // the two streaming sweeps share one launcher; the variant only changes the pipeline shape, never the result
 // which: 0 = XH^T (S = cells x genes copy, panel H), 1 = W^TX (S = genes x cells copy, panel W)
-static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g)
+static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
 {
+    SweepGeom g = g_in;
+    g.panel_fixed = c->ablate_panel ? 1 : 0;
     const float* master = which == 0 ? c->H : c->W;
     unsigned short* panel = which == 0 ? c->Hp16 : c->Wp16;
     const int64_t p_plane = (int64_t)g.R * c->KP;
-    // float32 master -> k-packed bf16 operand copy (rounded, or three exact planes)
-    int rc = launch_pack(c, master, c->KP, g.R, c->KP, panel, c->KP, 0, 0, 1, c->split ? 3 : 0, p_plane, nullptr);
-    if (rc) return rc;
+    // rounded mode: float32 master -> k-packed bf16 operand copy once per sweep; the split forms read the float32 master
+    // and split it into exact planes inside the sweep
+    if (!c->split) {
+        int rc = launch_pack(c, master, c->KP, g.R, c->KP, panel, c->KP, 0, 0, 1, 0, p_plane, nullptr);
+        if (rc) return rc;
+    }
     const unsigned short* S = which == 0 ? c->Xng16 : c->Xgn16;
     float* pieces = which == 0 ? c->piecesA : c->piecesB;
-#define BF_LAUNCH(NPX, NPP) \
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, \
-                                           (which == 0 ? c->x_plane_ng : c->x_plane_gn), \
-                                           panel, p_plane, pieces, g))
+#define BF_ARGS S, (which == 0 ? c->x_plane_ng : c->x_plane_gn), panel, p_plane, master, pieces, g
+#define BF_LAUNCH(NPX, NPP) do { \
+        if (g.bf == 8 * SG_WAVE_F) {          /* 8 waves: K <= 64 only (create_impl) */ \
+            if (c->KT == 1) hipLaunchKernelGGL((stream_gemm_bf16_kernel<1, NPX, NPP, 8>), dim3(g.nwg), dim3(512), 0, c->stream, BF_ARGS); \
+            else            hipLaunchKernelGGL((stream_gemm_bf16_kernel<2, NPX, NPP, 8>), dim3(g.nwg), dim3(512), 0, c->stream, BF_ARGS); \
+        } else { \
+            DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP, 4>), dim3(g.nwg), dim3(256), 0, c->stream, BF_ARGS)); \
+        } } while (0)
     if (!c->split) { BF_LAUNCH(1, 1); }
     else if (c->npx == 1) { BF_LAUNCH(1, 3); }
     else { BF_LAUNCH(2, 3); }
 #undef BF_LAUNCH
+#undef BF_ARGS
     HIPCHK(c, hipGetLastError());
     return 0;
 }

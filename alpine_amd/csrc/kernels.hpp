@@ -100,15 +100,17 @@ __device__ __forceinline__ void sg_stage(f32x16 (&acc)[KT][4], f32x4 (&x)[SG_RIN
 // Work division ("stream-K"): the (f tile, row) space of nft * R rows is cut into equal contiguous spans of L rows,
 // one per workgroup of a fixed grid (2 x #CU at K <= 64), so every workgroup executes the same number of MFMAs and
 // there is no ragged last round.  A span may cross tile boundaries; the workgroup writes one partial piece per tile
-// it touches: piece(w, j) = pieces[((w * maxp + j) * 512 + f_local) * KP + k], j = tile - first tile of w.  Consumers
+// it touches: piece(w, j) = pieces[((w * maxp + j) * bf + f_local) * KP + k], j = tile - first tile of w.  Consumers
 // sum a tile's pieces in ascending w (sg_tile_pieces below): fixed order, no atomics, bitwise reproducible.
 struct SweepGeom {
     int F;        // free extent, multiple of 128 (leading dimension of S)
     int R;        // contraction rows, multiple of SG_ROW_ALIGN
-    int nft;      // 512-wide f tiles
+    int bf;       // f columns per workgroup tile: 128 per wave (512 with 4 waves; 1024 for the 8-wave bf16 sweeps)
+    int nft;      // bf-wide f tiles
     int L;        // rows of (tile,row) space per workgroup, multiple of SG_ROW_ALIGN
     int nwg;      // workgroups
     int maxp;     // pieces per workgroup
+    int panel_fixed;  // timing-only ablation of the bf16 sweeps: every panel stage re-reads stage 0 (cache-resident) -> wrong results
 };
 
 // pieces that contribute to tile ft: workgroups w_lo..w_hi; piece index of w for this tile
@@ -120,7 +122,7 @@ __device__ __forceinline__ void sg_tile_pieces(const SweepGeom& g, int ft, int& 
 __device__ __forceinline__ int64_t sg_piece_offset(const SweepGeom& g, int w, int ft, int KP)
 {
     const int first = (int)(((int64_t)w * g.L) / g.R);
-    return ((int64_t)w * g.maxp + (ft - first)) * SG_BLOCK_F * KP;
+    return ((int64_t)w * g.maxp + (ft - first)) * g.bf * KP;
 }
 
 // SG_RING = X register ring depth in MFMA k-steps (= prefetch distance); SG_PASSES = ring passes per panel stage
@@ -274,7 +276,7 @@ void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ 
     const int64_t n4 = (int64_t)rows * kq;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int f = (int)(i / kq), k4 = (int)(i % kq);
-        const int ft = f / SG_BLOCK_F, fl = f % SG_BLOCK_F;
+        const int ft = f / g.bf, fl = f % g.bf;
         int w_lo, w_hi;
         sg_tile_pieces(g, ft, w_lo, w_hi);
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -622,7 +624,7 @@ void h_update_kernel(float* __restrict__ H, const float* __restrict__ pieces, Sw
     const int64_t n0 = (int64_t)gw * UPD_ROWS;
     float hv[UPD_ROWS][NH], xv[UPD_ROWS][NH], den[UPD_ROWS][NH];
     // the wave's 8 cells share one 512-cell tile of the W^TX sweep: sum that tile's pieces in ascending workgroup
-    const int ft = (int)(n0 / SG_BLOCK_F), fl0 = (int)(n0 % SG_BLOCK_F);
+    const int ft = (int)(n0 / g.bf), fl0 = (int)(n0 % g.bf);
     int w_lo, w_hi;
     sg_tile_pieces(g, ft, w_lo, w_hi);
 #pragma unroll
@@ -756,7 +758,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     if (n0 >= N) return;
     const int64_t n = n0 + c;
     const bool valid = n < N;
-    const int ft = (int)(n0 / SG_BLOCK_F), fl = (int)(n0 % SG_BLOCK_F) + c;
+    const int ft = (int)(n0 / g.bf), fl = (int)(n0 % g.bf) + c;
     int w_lo, w_hi;
     sg_tile_pieces(g, ft, w_lo, w_hi);
 
@@ -950,7 +952,7 @@ void h_iterate_mfma_kernel(float* __restrict__ H, const float* __restrict__ piec
     if (n0 >= N) return;
     const int64_t n = n0 + c;
     const bool valid = n < N;
-    const int ft = (int)(n0 / SG_BLOCK_F), fl = (int)(n0 % SG_BLOCK_F) + c;
+    const int ft = (int)(n0 / g.bf), fl = (int)(n0 % g.bf) + c;
     int w_lo, w_hi;
     sg_tile_pieces(g, ft, w_lo, w_hi);
 

@@ -163,63 +163,88 @@ void pack_split_kernel(const float* __restrict__ src, int64_t ld_src, int rows, 
 //   NPX = 1, NPP = 3 : X exactly one bf16 plane (small integer counts), panel exact in 3 planes -> float32-grade result, 3 MFMAs
 //   NPX = 2, NPP = 3 : X exact in two planes (16 significant bits), 5 MFMAs
 // bf16 x bf16 products are exact in float32, so the split forms differ from the float32 MFMA path only in summation order.
-// Same stream-K work division, pieces and wave tiling (4 waves x 128 f columns x all KP) as the float32 kernel.  One
+// Same stream-K work division, pieces and wave tiling (NW waves x 128 f columns x all KP) as the float32 kernel; NW = 8
+// (one 512-thread workgroup per CU, 1024-column tiles) halves the panel re-reads of NW = 4.  One
 // k-step = 16 rows = one v_mfma_f32_32x32x16_bf16 depth; per k-step and X plane a wave issues 4 loads of 1 KiB.  The
 // X ring holds BF_RING k-steps (16 KiB per wave in flight in every variant); one panel stage per ring pass.
 template <int KT, int NPX, int NPP, int BF_RING, bool LAST>
 __device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RING][NPX][4], const unsigned short* __restrict__ lrow,
                                          const unsigned short* __restrict__ xnext, int64_t f_stride8, int64_t x_plane, int lds_plane)
 {
+    // Order inside a k-step: tile j outermost, so that the X register of tile j is dead after its NPP*KT (one-plane X)
+    // MFMAs and is refilled at once -- a ring slot is in flight for (ring period - one tile's MFMAs) instead of (ring
+    // period - one k-step's MFMAs): with the split forms' 3-5 MFMAs per load that is 7/8 instead of 1/2 of the ring in
+    // flight, for the same registers.  A fragments (all panel planes of the k-step): double-buffered over k-steps when
+    // there is one plane; with 3 planes a single set, each fragment re-read from LDS right after its last use (tile 3).
     constexpr int KP = 32 * KT;
-    constexpr int UNITS = BF_RING * NPP;               // (k-step, panel plane) units; A fragments are prefetched one unit ahead
-    u32x4 a[2][KT];
+    constexpr int NB = NPP == 1 ? 2 : 1;
+    u32x4 a[NB][NPP][KT];
+    auto lda = [&](int p, int pp, int m) {
+        return *reinterpret_cast<const u32x4*>(lrow + pp * lds_plane + ((2 * p) * KP + 32 * m) * 8);
+    };
 #pragma unroll
-    for (int m = 0; m < KT; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(lrow + (32 * m) * 8);
+    for (int pp = 0; pp < NPP; ++pp)
 #pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int p = u / NPP, pp = u % NPP;
-        if (u + 1 < UNITS) {
-            const int p1 = (u + 1) / NPP, pp1 = (u + 1) % NPP;
+        for (int m = 0; m < KT; ++m) a[0][pp][m] = lda(0, pp, m);
 #pragma unroll
-            for (int m = 0; m < KT; ++m)
-                a[(u + 1) & 1][m] = *reinterpret_cast<const u32x4*>(lrow + pp1 * lds_plane + ((2 * p1) * KP + 32 * m) * 8);
+    for (int p = 0; p < BF_RING; ++p) {
+        const int cur = NB == 2 ? (p & 1) : 0;
+        if (NB == 2 && p + 1 < BF_RING) {
+#pragma unroll
+            for (int pp = 0; pp < NPP; ++pp)
+#pragma unroll
+                for (int m = 0; m < KT; ++m) a[cur ^ 1][pp][m] = lda(p + 1, pp, m);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int xp = 0; xp < NPX; ++xp) {
-            if (xp + pp <= NPP - 1) {
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int m = 0; m < KT; ++m)
+            for (int pp = 0; pp < NPP; ++pp) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[u & 1][m]),
-                                                                            __builtin_bit_cast(bf16x8, x[p][xp][j]), acc[m][j], 0, 0, 0);
+                for (int xp = 0; xp < NPX; ++xp) {
+                    if (xp + pp <= NPP - 1) {
+#pragma unroll
+                        for (int m = 0; m < KT; ++m)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][pp][m]),
+                                                                                __builtin_bit_cast(bf16x8, x[p][xp][j]), acc[m][j], 0, 0, 0);
+                    }
+                }
+                if (NB == 1 && j == 3 && p + 1 < BF_RING) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < KT; ++m) a[0][pp][m] = lda(p + 1, pp, m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
-        if (!LAST && pp == NPP - 1) {                  // last use of x[p][*]: refill the ring slot for the next stage
+            __builtin_amdgcn_sched_barrier(0);
+            if (!LAST) {
 #pragma unroll
-            for (int xp = 0; xp < NPX; ++xp)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int xp = 0; xp < NPX; ++xp)
                     x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xnext + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int KT, int NPX, int NPP>
-__global__ __launch_bounds__(SG_THREADS, (KT <= 2 ? 2 : 1))
+template <int KT, int NPX, int NPP, int NW>
+__global__ __launch_bounds__(64 * NW, (KT <= 2 && NW == 4 ? 2 : 1))
 void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_plane, const unsigned short* __restrict__ P,
-                             int64_t p_plane, float* __restrict__ pieces, SweepGeom g)
+                             int64_t p_plane, const float* __restrict__ Pf, float* __restrict__ pieces, SweepGeom g)
 {
+    // Panel source: NPP == 1 reads the rounded bf16 k-packed copy P (made by pack_bf16_kernel once per sweep);
+    // NPP == 3 reads the float32 master Pf[R][KP] directly and splits it into its three exact bf16 planes while
+    // staging it into LDS (4 instead of 6 bytes per panel element through the fabric, and no pack pass: every
+    // workgroup re-reads the panel rows of its span, which is ~1/4 of the sweep's fabric traffic in the split forms).
     constexpr int KP = 32 * KT;
+    constexpr int NT = 64 * NW;                                     // threads: NW waves x 128 f columns share one panel stage
     constexpr int BF_RING = NPP == 1 ? 4 : 2;                       // k-steps in the X ring (rounded bf16: 16 loads in flight;
                                                                     // split forms: 8 or 16 loads, 3-5x the MFMA work per load)
     constexpr int BF_ROWS = 16 * BF_RING;                           // rows per panel stage
     static_assert(SG_ROW_ALIGN % BF_ROWS == 0, "stream-K spans are multiples of one stage");
     constexpr int STAGE_BF16 = BF_ROWS * KP;                        // bf16 elements of one panel stage, per plane
     constexpr int GRAN = STAGE_BF16 / 8;                            // 16-byte granules per plane per stage
-    constexpr int PV = (NPP * GRAN + SG_THREADS - 1) / SG_THREADS;  // granules per thread per stage
+    constexpr int PV = NPP == 1 ? (GRAN + NT - 1) / NT : 1;     // granules per thread per stage (bf16 panel copy)
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][NPP * STAGE_BF16];
 
     const int tid = threadIdx.x;
@@ -233,7 +258,8 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
     const int first_tile = (int)(pos / g.R);
     const int64_t f_stride8 = (int64_t)g.F * 8;                     // bf16 elements between consecutive 8-row blocks of S
 
-    u32x4 preg[PV];
+    u32x4 preg[PV];                                                 // NPP == 1: staged bf16 granules
+    float pf[NPP == 1 ? 1 : ((BF_ROWS / 8) * KP + NT - 1) / NT][8];   // NPP == 3: staged float32 panel values
     u32x4 x[BF_RING][NPX][4];
 
     while (pos < pos_end) {
@@ -242,25 +268,57 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
         const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
         pos += r_end - r_begin;
         const int nst = (r_end - r_begin) / BF_ROWS;
-        const int f0 = (ft * SG_WAVES + wave) * SG_WAVE_F;
+        const int f0 = (ft * NW + wave) * SG_WAVE_F;
         const bool active = f0 < g.F;
 
-        const unsigned short* pptr = P + (int64_t)(r_begin / 8) * KP * 8;
+        constexpr int SETS = (BF_ROWS / 8) * KP;                   // (8-row block, column) granule positions of one stage
+        constexpr int PVS = (SETS + NT - 1) / NT;
+        const unsigned short* pptr = P + (g.panel_fixed ? (int64_t)0 : (int64_t)(r_begin / 8) * KP * 8);
+        const float* pfptr = Pf + (g.panel_fixed ? (int64_t)0 : (int64_t)r_begin * KP);
         auto load_p = [&](int t) {
+            if constexpr (NPP == 1) {
 #pragma unroll
-            for (int v = 0; v < PV; ++v) {
-                const int gi = tid + SG_THREADS * v;                // granule index over planes
-                if (NPP * GRAN % SG_THREADS == 0 || gi < NPP * GRAN) {
-                    const int pl = gi / GRAN, gq = gi % GRAN;
-                    preg[v] = *reinterpret_cast<const u32x4*>(pptr + pl * p_plane + (int64_t)t * STAGE_BF16 + 8 * gq);
+                for (int v = 0; v < PV; ++v) {
+                    const int gi = tid + NT * v;                // granule index
+                    if (GRAN % NT == 0 || gi < GRAN)
+                        preg[v] = *reinterpret_cast<const u32x4*>(pptr + (int64_t)(g.panel_fixed ? 0 : t) * STAGE_BF16 + 8 * gi);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < PVS; ++v) {
+                    const int si = tid + NT * v;                // set index = rb * KP + col
+                    if (SETS % NT == 0 || si < SETS) {
+                        const int rb = si / KP, col = si % KP;
+                        const float* src = pfptr + ((int64_t)(g.panel_fixed ? 0 : t) * BF_ROWS + 8 * rb) * KP + col;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[v][e] = src[e * KP];
+                    }
                 }
             }
         };
         auto store_p = [&](int b) {
+            if constexpr (NPP == 1) {
 #pragma unroll
-            for (int v = 0; v < PV; ++v) {
-                const int gi = tid + SG_THREADS * v;
-                if (NPP * GRAN % SG_THREADS == 0 || gi < NPP * GRAN) *reinterpret_cast<u32x4*>(&lds[b][8 * gi]) = preg[v];
+                for (int v = 0; v < PV; ++v) {
+                    const int gi = tid + NT * v;
+                    if (GRAN % NT == 0 || gi < GRAN) *reinterpret_cast<u32x4*>(&lds[b][8 * gi]) = preg[v];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < PVS; ++v) {
+                    const int si = tid + NT * v;
+                    if (SETS % NT == 0 || si < SETS) {
+                        unsigned short pl[3][8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f32_split3(pf[v][e], pl[0][e], pl[1][e], pl[2][e]);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            u32x4 o = {(unsigned)pl[q][0] | ((unsigned)pl[q][1] << 16), (unsigned)pl[q][2] | ((unsigned)pl[q][3] << 16),
+                                       (unsigned)pl[q][4] | ((unsigned)pl[q][5] << 16), (unsigned)pl[q][6] | ((unsigned)pl[q][7] << 16)};
+                            *reinterpret_cast<u32x4*>(&lds[b][q * STAGE_BF16 + 8 * si]) = o;
+                        }
+                    }
+                }
             }
         };
 
@@ -321,7 +379,7 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
         bf_stage<KT, NPX, NPP, BF_RING, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = 128*wave + 32*j + c
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * SG_BLOCK_F + wave * SG_WAVE_F + c) * KP + 4 * h;
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * (NW * SG_WAVE_F) + wave * SG_WAVE_F + c) * KP + 4 * h;
 #pragma unroll
         for (int m = 0; m < KT; ++m)
 #pragma unroll

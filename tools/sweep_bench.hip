@@ -14,6 +14,7 @@ static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced)     // s
 {
     SweepGeom g{};
     g.F = (int)F; g.R = (int)R;
+    g.bf = SG_BLOCK_F;
     g.nft = (int)((F + SG_BLOCK_F - 1) / SG_BLOCK_F);
     const int64_t total = (int64_t)g.nft * R;
     int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
