@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libalpine_hip.so")
 LOSS_KL, LOSS_FROBENIUS = 0, 1
 X_CELLS_BY_GENES, X_GENES_BY_CELLS = 0, 1
 KERNEL_SWEEP_XHT, KERNEL_SWEEP_WTX = 0, 1
-FLAG_TRANSFORM_ONLY, FLAG_X_BF16, FLAG_USE_ALS, FLAG_X_SPLIT = 1, 2, 4, 8
+FLAG_TRANSFORM_ONLY, FLAG_X_BF16, FLAG_USE_ALS, FLAG_X_SPLIT, FLAG_X3_PRODUCTS = 1, 2, 4, 8, 16
 BUF_REDUCE_BLOCK, BUF_WTW, BUF_W, BUF_H, BUF_X_GN, BUF_X_NG = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
@@ -118,8 +118,8 @@ class NativeShard:
                  device_id: int = 0, stream: Optional[int] = None, reduce_block: Optional[int] = None,
                  split_a: int = 0, split_b: int = 0, transform_only: bool = False, x_dtype: str = "f32",
                  batch_capacity: int = 0, use_als: bool = False):
-        if x_dtype not in ("f32", "bf16", "split"):
-            raise ValueError("x_dtype must be 'f32', 'bf16' or 'split'")
+        if x_dtype not in ("f32", "bf16", "split", "x3"):
+            raise ValueError("x_dtype must be 'f32', 'bf16', 'split' or 'x3'")
         self._lib = load()
         self._h = C.c_void_p()
         n_cov = len(cov_components)
@@ -134,7 +134,7 @@ class NativeShard:
         cfg.cov_components, cfg.cov_levels, cfg.lam = self._k, self._lev, self._lam
         cfg.orth_W, cfg.alpha_W, cfg.l1_ratio_W, cfg.eps = orth_W, alpha_W, l1_ratio_W, eps
         cfg.loss_type = LOSS_KL if loss_type == "kl-divergence" else LOSS_FROBENIUS
-        cfg.split_a, cfg.split_b, cfg.flags = split_a, split_b, ((FLAG_TRANSFORM_ONLY if transform_only else 0) | (FLAG_X_BF16 if x_dtype == "bf16" else 0) | (FLAG_X_SPLIT if x_dtype == "split" else 0) |
+        cfg.split_a, cfg.split_b, cfg.flags = split_a, split_b, ((FLAG_TRANSFORM_ONLY if transform_only else 0) | (FLAG_X_BF16 if x_dtype == "bf16" else 0) | (FLAG_X_SPLIT if x_dtype == "split" else 0) | (FLAG_X3_PRODUCTS if x_dtype == "x3" else 0) |
                                                        (FLAG_USE_ALS if use_als else 0))
         cfg.stream = stream
         cfg.reduce_block = reduce_block

@@ -3,6 +3,7 @@
 #include "../../include/alpine_hip.h"
 #include "kernels.hpp"
 #include "kernels_bf16.hpp"
+#include "kernels_x3.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -59,6 +60,9 @@ struct alpine_ctx {
     float *Xb_gn = nullptr, *Xb_ng = nullptr, *Hb = nullptr, *Yb = nullptr;
     int* idx_dev = nullptr;
     int slots = 512;
+    bool x3 = false;                  // ALPINE_FLAG_X3_PRODUCTS in effect (float32 X, exact bf16 plane products)
+    int64_t piecesA_cap = 0, piecesB_cap = 0;   // capacity of the pieces buffers, in (bf x KP) tiles
+    int sweep_bf = SG_BLOCK_F;        // f columns per sweep workgroup tile (SweepGeom::bf of every geometry of this ctx)
     int sweep_waves = 4;              // waves per sweep workgroup (8 for the bf16 sweeps with K <= 64)
     float* red = nullptr;
     bool own_red = false;
@@ -225,6 +229,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->npx = c->split ? 2 : 1;        // two planes until alpine_finalize_X knows whether the second is needed
     c->npp = c->split ? 3 : 1;
     c->use_als = (cfg->flags & ALPINE_FLAG_USE_ALS) != 0;
+    c->x3 = (cfg->flags & ALPINE_FLAG_X3_PRODUCTS) != 0 && !c->bf16;
     c->device = cfg->device_id;
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -258,11 +263,13 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     // sweeps
     // bf16 sweeps with K <= 64: 8-wave workgroups (1024-column tiles, one per CU); everything else 4 waves x 512 columns
     c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;
-    const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 ? 2 : 1);
+    const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
     c->slots = slots;
+    const int sweep_bf = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
+    c->sweep_bf = sweep_bf;
     c->batch_cap = cfg->batch_capacity;
-    c->geomA = make_geom(Gp, Np, slots, cfg->split_a, c->sweep_waves * SG_WAVE_F);       // XH^T: f = genes, r = cells
-    c->geomB = make_geom(Np, Gp, slots, cfg->split_b, c->sweep_waves * SG_WAVE_F);       // W^TX: f = cells, r = genes
+    c->geomA = make_geom(Gp, Np, slots, cfg->split_a, sweep_bf);       // XH^T: f = genes, r = cells
+    c->geomB = make_geom(Np, Gp, slots, cfg->split_b, sweep_bf);       // W^TX: f = cells, r = genes
 
     ALLOC(c, c->Xgn, float, c->bf16 ? 4 : Gp * Np);
     ALLOC(c, c->Xng, float, (c->transform_only || c->bf16) ? 4 : Np * Gp);
@@ -285,8 +292,15 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
     ALLOC(c, c->B[0], float, std::max(1, c->nB));
     ALLOC(c, c->B[1], float, std::max(1, c->nB));
-    ALLOC(c, c->piecesA, float, c->transform_only ? 4 : (int64_t)c->geomA.nwg * c->geomA.maxp * c->geomA.bf * KP);
-    ALLOC(c, c->piecesB, float, (int64_t)c->geomB.nwg * c->geomB.maxp * c->geomB.bf * KP);
+    // pieces: nwg * maxp tiles of bf x KP; mini-batch views have their own geometry, bounded by nft + 2 * nwg + maxp pieces
+    c->piecesA_cap = (int64_t)c->geomA.nwg * c->geomA.maxp;
+    c->piecesB_cap = (int64_t)c->geomB.nwg * c->geomB.maxp;
+    if (c->batch_cap > 0) {
+        c->piecesA_cap = std::max<int64_t>(c->piecesA_cap, (int64_t)c->geomA.nft + 2 * slots + 8);
+        c->piecesB_cap = std::max<int64_t>(c->piecesB_cap, (int64_t)c->geomB.nft + 2 * slots + 8);
+    }
+    ALLOC(c, c->piecesA, float, c->transform_only ? 4 : c->piecesA_cap * sweep_bf * KP);
+    ALLOC(c, c->piecesB, float, c->piecesB_cap * sweep_bf * KP);
     c->red_floats = g.red_floats; c->red_hht = g.red_hht; c->red_stats = g.red_stats;
     if (cfg->reduce_block) { c->red = (float*)cfg->reduce_block; c->own_red = false; HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream)); }
     else { ALLOC(c, c->red, float, c->red_floats); c->own_red = true; }
@@ -660,6 +674,16 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
 {
     if (c->bf16) return launch_sweep_bf16(c, which, g);
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
+    if (c->x3) {
+        switch (c->KT) {
+            case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
+            case 2: hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
+            case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
+            default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
+        }
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
 #define SG_LAUNCH(RING, PASSES) \
     DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_kernel<KT_, RING, PASSES>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, P, pieces, ldS, g, (unsigned long long*)nullptr))
     switch (c->sg_variant) {
@@ -865,8 +889,10 @@ extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
     CellView v;
     v.Xgn = c->Xb_gn; v.Xng = c->Xb_ng; v.H = c->Hb; v.Y = c->Yb;
     v.N = (int)n; v.Np = Bp;
-    v.gA = make_geom(c->Gp, Bp, c->slots, 0);
-    v.gB = make_geom(Bp, c->Gp, c->slots, 0);
+    v.gA = make_geom(c->Gp, Bp, c->slots, 0, c->sweep_bf);
+    v.gB = make_geom(Bp, c->Gp, c->slots, 0, c->sweep_bf);
+    if ((int64_t)v.gA.nwg * v.gA.maxp > c->piecesA_cap || (int64_t)v.gB.nwg * v.gB.maxp > c->piecesB_cap)
+        return fail(c, ALPINE_ERR_STATE, "internal: batch view needs more sweep pieces than were allocated");
     v.statBlocks = (int)((n + HS_CELLS - 1) / HS_CELLS);
     v.gramBlocksH = (int)((Bp + 4 * GR_ROWS_PER_WAVE - 1) / (4 * GR_ROWS_PER_WAVE));
     if ((rc = phase1(c, v))) return rc;

@@ -1,0 +1,238 @@
+// Float32-grade sweeps on the bf16 matrix pipe for ARBITRARY float32 X ("x3"): out[f][k] = sum_r S[r][f] * P[r][k].
+//
+// A bf16 x bf16 product is exact in float32, and every float32 is exactly the sum of three bf16 planes (8 + 8 + 8
+// significand bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)).  So
+//     x * p = sum_{a,b} x_a * p_b ,   and the six terms with a + b <= 2 carry everything above 2^-24 |x p|
+// (the three dropped terms are each below one float32 rounding of the product).  The float32 MFMA executes at the
+// float32 vector rate (157 TF: tools/coissue.hip); six bf16 MFMAs cost 6/16 of one float32 MFMA, so the sweep turns
+// from MFMA-bound (3.05 ms per launch at cfg3) into HBM-bound (16 GB: 2.0 ms at 8 TB/s) while X stays float32 in HBM,
+// unlike the pre-split storage of kernels_bf16.hpp (which needs X to be exactly one or two planes).
+//
+// X is streamed as float32 exactly like stream_gemm_kernel (one global_load_dwordx4 per lane = 4 interleaved tiles,
+// tile t / column j <-> f0 + 4j + t) and split into its planes IN REGISTERS right before use; the panel (W or H,
+// float32 master) is split while it is staged into LDS, as in the NPP = 3 form of stream_gemm_bf16_kernel.
+//
+// Tiling: 4 waves per workgroup, ONE workgroup per CU (1 wave per SIMD, up to 512 registers per lane).  A wave owns
+// NH halves of 128 f columns x all KP components = 4*NH x KT accumulator tiles of v_mfma_f32_32x32x16_bf16 -- 256
+// accumulator registers in both shapes: K <= 64 -> NH = 2 (256 columns per wave, 1024-column workgroup tiles: half the
+// panel re-reads of 512-column tiles), K <= 128 -> NH = 1.  Ring of 2 k-steps (16 rows each) of float32 X: 16 KiB per
+// half in flight per wave.  Six bf16 MFMAs per fragment pair cost 6/16 of one float32 MFMA, so the sweep stays near the
+// HBM bound up to K = 128 while the float32-MFMA sweep's time grows with K.
+#pragma once
+#include "kernels_bf16.hpp"
+
+namespace alpine {
+
+constexpr int X3_RING = 2;                  // k-steps in the X ring
+constexpr int X3_ROWS = 16 * X3_RING;       // rows per panel stage
+
+// exact planes of 8 consecutive rows of one column, packed as MFMA B operands (8 bf16 = 4 dwords per plane)
+__device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 (&b)[3])
+{
+    unsigned short pl[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f32_split3(v[e], pl[0][e], pl[1][e], pl[2][e]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        b[q] = u32x4{(unsigned)pl[q][0] | ((unsigned)pl[q][1] << 16), (unsigned)pl[q][2] | ((unsigned)pl[q][3] << 16),
+                     (unsigned)pl[q][4] | ((unsigned)pl[q][5] << 16), (unsigned)pl[q][6] | ((unsigned)pl[q][7] << 16)};
+}
+
+// One panel stage = X3_RING k-steps.  Per k-step: A fragments of all three panel planes (double-buffered over k-steps),
+// then per 128-column half: 4 x (split one tile's 8 x float32 into planes, 6*KT MFMAs), then the half's 8 loads are
+// re-issued for the same k-step of the next stage.
+template <int KT, int NH, bool LAST>
+__device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X3_RING][NH][8], const unsigned short* __restrict__ lrow,
+                                         const float* __restrict__ xnext0, const float* __restrict__ xnext1, int64_t ldS, int lds_plane)
+{
+    constexpr int KP = 32 * KT;
+    u32x4 a[2][3][KT];
+    auto lda = [&](int p, int pp, int m) {
+        return *reinterpret_cast<const u32x4*>(lrow + pp * lds_plane + ((2 * p) * KP + 32 * m) * 8);
+    };
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+        for (int m = 0; m < KT; ++m) a[0][pp][m] = lda(0, pp, m);
+#pragma unroll
+    for (int p = 0; p < X3_RING; ++p) {
+        const int cur = p & 1;
+        if (p + 1 < X3_RING) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int m = 0; m < KT; ++m) a[cur ^ 1][pp][m] = lda(p + 1, pp, m);
+        }
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x[p][hf][e][t];
+                u32x4 b[3];
+                x3_split8(v, b);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int xp = 0; xp + pp <= 2; ++xp)
+#pragma unroll
+                        for (int m = 0; m < KT; ++m)
+                            acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][pp][m]),
+                                                                                         __builtin_bit_cast(bf16x8, b[xp]), acc[m][4 * hf + t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!LAST) {
+                const float* src = (hf == 0 ? xnext0 : xnext1) + (int64_t)(16 * p) * ldS;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    x[p][hf][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (int64_t)e * ldS));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int KT, int NH>
+__global__ __launch_bounds__(256, 1)
+void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
+                           int64_t ldS, SweepGeom g)
+{
+    static_assert(KT * NH <= 4, "256 accumulator registers per lane");
+    constexpr int KP = 32 * KT;
+    constexpr int WAVE_F = 128 * NH, BLOCK_F = 4 * WAVE_F;
+    constexpr int NT = 256;
+    static_assert(SG_ROW_ALIGN % X3_ROWS == 0, "stream-K spans are multiples of one stage");
+    constexpr int STAGE_BF16 = X3_ROWS * KP;                        // bf16 elements of one panel stage, per plane
+    constexpr int SETS = (X3_ROWS / 8) * KP;                        // (8-row block, column) granule positions of one stage
+    constexpr int PVS = (SETS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * STAGE_BF16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int w = blockIdx.x;
+    const int64_t total = (int64_t)g.nft * g.R;
+    int64_t pos = (int64_t)w * g.L;
+    const int64_t pos_end = min(total, pos + g.L);
+    const int first_tile = (int)(pos / g.R);
+
+    float pf[PVS][8];
+    f32x4 x[X3_RING][NH][8];
+
+    while (pos < pos_end) {
+        const int ft = (int)(pos / g.R);
+        const int r_begin = (int)(pos - (int64_t)ft * g.R);
+        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
+        pos += r_end - r_begin;
+        const int nst = (r_end - r_begin) / X3_ROWS;
+        const int f0 = (ft * 4 + wave) * WAVE_F;
+        const bool active = f0 < g.F;
+        // F is a multiple of 128, not of 256: a wave whose second half lies outside re-reads its first half there (valid
+        // memory; those accumulators land in piece columns >= F, which no consumer reads)
+        const int f1 = (NH == 2 && f0 + 128 < g.F) ? f0 + 128 : f0;
+
+        const float* pfptr = Pf + (int64_t)r_begin * KP;
+        auto load_p = [&](int t) {
+#pragma unroll
+            for (int v = 0; v < PVS; ++v) {
+                const int si = tid + NT * v;                        // set index = rb * KP + col
+                if (SETS % NT == 0 || si < SETS) {
+                    const int rb = si / KP, col = si % KP;
+                    const float* src = pfptr + ((int64_t)t * X3_ROWS + 8 * rb) * KP + col;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[v][e] = src[e * KP];
+                }
+            }
+        };
+        auto store_p = [&](int b) {
+#pragma unroll
+            for (int v = 0; v < PVS; ++v) {
+                const int si = tid + NT * v;
+                if (SETS % NT == 0 || si < SETS) {
+                    u32x4 o[3];
+                    x3_split8(pf[v], o);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&lds[b][q * STAGE_BF16 + 8 * si]) = o[q];
+                }
+            }
+        };
+
+        __syncthreads();
+        load_p(0);
+        store_p(0);
+        if (nst > 1) load_p(1);
+
+        if (!active) {
+            __syncthreads();
+            for (int t = 0; t + 1 < nst; ++t) {
+                store_p((t + 1) & 1);
+                if (t + 2 < nst) load_p(t + 2);
+                __syncthreads();
+            }
+            continue;
+        }
+
+        f32x16 acc[KT][4 * NH];
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+            for (int j = 0; j < 4 * NH; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+        // this lane's float4 of row r_begin + 8h (+ e), columns f + 4c..4c+3 (element t -> tile t, column c)
+        const float* xrow0 = S + (int64_t)(r_begin + 8 * h) * ldS + f0 + 4 * c;
+        const float* xrow1 = S + (int64_t)(r_begin + 8 * h) * ldS + f1 + 4 * c;
+        const int64_t x_stage = (int64_t)X3_ROWS * ldS;
+        const int lds_lane = (h * KP + c) * 8;
+
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < X3_RING; ++p)
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    x[p][hf][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((hf == 0 ? xrow0 : xrow1) + (int64_t)(16 * p + e) * ldS));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+
+        int t = 0;
+        for (; t + 2 < nst; ++t) {
+            store_p((t + 1) & 1);
+            load_p(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            x3_stage<KT, NH, false>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
+            __syncthreads();
+        }
+        if (t + 1 < nst) {
+            store_p((t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            x3_stage<KT, NH, false>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
+            __syncthreads();
+            ++t;
+        }
+        x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
+
+        // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F + 4 * c) * KP + 4 * h;
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            if (hf == 1 && f1 == f0) break;                          // second half outside F: nothing to write
+#pragma unroll
+            for (int m = 0; m < KT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const f32x16& d = acc[m][4 * hf + tt];
+                        f32x4 v = {d[4 * q + 0], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(out + (int64_t)(128 * hf + tt) * KP + 32 * m + 8 * q) = v;
+                    }
+        }
+    }
+}
+
+}  // namespace alpine

@@ -65,7 +65,7 @@ class ALPINE:
         eps: float = 1e-6,
         random_state: int = 42,
         shard_cells: bool = False,
-        x_dtype: str = "f32",
+        x_dtype: str = "x3",
     ):
         self.n_components = n_components
         self.n_covariate_components = n_covariate_components
@@ -85,13 +85,18 @@ class ALPINE:
         # extension (not in the reference): shard the cell axis over the ranks of the default
         # torch.distributed process group, one process per GPU.  Default: single device.
         self.shard_cells = shard_cells
-        # extension: storage / matrix-pipe mode of the two sweeps.  "f32" (default) is the reference's arithmetic on the
-        # float32 MFMA.  "bf16" rounds X and the operand copies of W/H to bf16 (fp32 accumulation, fp32 masters).
-        # "split" keeps X as 1-2 bf16 planes that sum EXACTLY to the input and W/H operands as 3 exact planes: float32-grade
-        # results on the bf16 matrix pipe; raises if X is not exactly representable (more than 16 significant bits).
-        # "auto" = "split" when X allows it, else "f32".
-        if x_dtype not in ("f32", "bf16", "split", "auto"):
-            raise ValueError("x_dtype must be 'f32', 'bf16', 'split' or 'auto'")
+        # extension: storage / matrix-pipe mode of the two sweeps (the reference has float32 only).
+        #   "x3" (default)  X float32 in HBM; every product is formed from the exact bf16 planes of both factors on the
+        #                   bf16 matrix pipe (six plane products, float32 accumulate): float32-grade results for ANY X at
+        #                   HBM-bound instead of float32-MFMA-bound speed.
+        #   "f32"           the float32 MFMA (v_mfma_f32_32x32x2_f32) on the same float32 storage.
+        #   "split"         X stored as 1-2 bf16 planes that sum EXACTLY to the input (integer counts): float32-grade
+        #                   results at half the memory and traffic; raises if X has more than 16 significant bits.
+        #   "auto"          "split" when X allows it, else "x3".
+        #   "bf16"          X and the operand copies of W/H rounded to bf16 (fp32 accumulation, fp32 masters): NOT
+        #                   float32-grade, tolerance in DESIGN.md.
+        if x_dtype not in ("f32", "x3", "bf16", "split", "auto"):
+            raise ValueError("x_dtype must be 'f32', 'x3', 'bf16', 'split' or 'auto'")
         self.x_dtype = x_dtype
 
         self._validate_init_args()
@@ -153,8 +158,8 @@ class ALPINE:
         if self._uses_batches(n_sample):
             if self.shard_cells:
                 raise NotImplementedError("mini-batch / weighted sampling is single-device for now (no shard_cells)")
-            if self.x_dtype not in ("f32", "auto"):
-                raise NotImplementedError("mini-batch / weighted sampling needs x_dtype='f32' (or 'auto')")
+            if self.x_dtype not in ("f32", "x3", "auto"):
+                raise NotImplementedError("mini-batch / weighted sampling needs float32 storage: x_dtype='f32', 'x3' or 'auto'")
 
     def _uses_batches(self, n_sample: int) -> bool:
         """Full batch with the 'random' permutation is the in-place fast path (the permutation only re-orders sums);
@@ -185,7 +190,7 @@ class ALPINE:
 
         x_dtype = self.x_dtype
         if x_dtype == "auto":
-            x_dtype = "f32" if self._uses_batches(N_total) else "split"
+            x_dtype = "x3" if self._uses_batches(N_total) else "split"
         kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
@@ -220,10 +225,11 @@ class ALPINE:
         try:
             eng = make_engine(x_dtype)
         except _native.AlpineNativeError as err:
-            # "auto" only: X has more than 16 significant bits somewhere -> the exact split does not apply, use float32
+            # "auto" only: X has more than 16 significant bits somewhere -> the pre-split storage does not apply; keep X in
+            # float32 and split it inside the sweeps instead
             if not (self.x_dtype == "auto" and x_dtype == "split" and err.code == -5):
                 raise
-            x_dtype = "f32"
+            x_dtype = "x3"
             eng = make_engine(x_dtype)
         self.x_dtype_used = x_dtype
         try:
@@ -330,7 +336,7 @@ class ALPINE:
         except _native.AlpineNativeError as err:
             if not (self.x_dtype == "auto" and err.code == -5):
                 raise
-            eng = make_engine("f32")
+            eng = make_engine("x3")
         try:
             eng.set_factors(W, H0, [])
             eng.transform(n_iter)

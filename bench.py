@@ -5,16 +5,23 @@ A "step" is one full-batch multiplicative-update iteration (W, every B_i, H; alp
 INCLUDING its loss row (main.py:666) over one synthetic gene x cell matrix that is already resident
 in HBM when the timed region starts.  Workload at every GPU count = BASELINE.json's metric shape,
 "cfg3" of SURVEY.md 8d: 20 000 genes x 200 000 cells, K = 50 + [5, 5], 2 two-level covariates,
-lam = [1e3, 1e3], alpha_W = 1.0, orth_W = 0.1, l1_ratio_W = 0.5, KL loss, fp32.  With N GPUs the
-cell axis is sharded (one process per GPU, one RCCL all-reduce per iteration): strong scaling.
+lam = [1e3, 1e3], alpha_W = 1.0, orth_W = 0.1, l1_ratio_W = 0.5, KL loss, float32 X / W / H / B in HBM.
+With N GPUs the cell axis is sharded (one process per GPU, one RCCL all-reduce per iteration): strong scaling.
+
+Sweep modes (--dtype; all but "bf16" give float32-grade results):
+  x3 (default)  X float32; products formed from the exact bf16 planes of both factors (6 bf16 MFMAs per fragment
+                pair, float32 accumulate): no precondition on X, HBM-bound (4 B per element of X per sweep)
+  f32           the float32 MFMA on the same storage: MFMA-bound (reported under other_modes of the default run)
+  split         X pre-split into 1-2 exact bf16 planes at ingest (integer counts): HBM-bound at 2 B per element
+  bf16          operands ROUNDED to bf16 (BASELINE config 5), tolerance reported by the tests
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see the repo's driver contract) with two extra objects:
-  roofline     -- the dominant kernel (the MFMA streaming sweep, 2 launches/iteration): algorithmic
-                  flops per launch / average launch time measured live with hipEvents on the
-                  kernel's stream, against the fp32 MFMA peak (K >= 40 => MFMA-bound)
+  roofline     -- the dominant kernel (the streaming sweep, 2 launches/iteration): algorithmic bytes (or, for
+                  --dtype f32, flops) per launch / average launch time measured live with hipEvents on the
+                  kernel's stream, against the 8 TB/s HBM peak (f32: the 157.3 TF float32 MFMA peak)
   cpu_baseline -- the oracle's faithful torch-CPU restatement of the reference loop timed on this
                   host's cores on a bounded sample (fewer cells), extrapolated linearly in cells
 """
@@ -55,9 +62,10 @@ def parse_args():
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra (non-headline) split / bf16 measurements at N=1")
     ap.add_argument("--no-loss", action="store_true", help="updates only (secondary number)")
     ap.add_argument("--cpu-sample-cells", type=int, default=12000)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "split"],
-                    help="f32: float32 MFMA (reference arithmetic); bf16: operands rounded to bf16; split: exact bf16 planes of X and "
-                         "of the operands on the bf16 matrix pipe (float32-grade results; needs bf16-exact X such as counts)")
+    ap.add_argument("--dtype", default="x3", choices=["f32", "bf16", "split", "x3"],
+                    help="x3: float32 X, products from exact bf16 planes in the sweep (float32-grade, any X); f32: float32 MFMA; "
+                         "split: X pre-split into exact bf16 planes (float32-grade; needs bf16-exact X such as counts); "
+                         "bf16: operands rounded to bf16")
     ap.add_argument("--x-scale", type=float, default=1.0, help="multiply the synthetic counts (e.g. 300 -> values need two bf16 planes)")
     ap.add_argument("--split-a", type=int, default=0)
     ap.add_argument("--split-b", type=int, default=0)
@@ -122,7 +130,7 @@ def pmc_traffic(workload: str, world: int, kp: int, dtype: str = "f32"):
         return None
     best = None
     import re
-    tag = {"f32": "", "bf16": "_bf16", "split": "_split"}[dtype]
+    tag = {"f32": "", "bf16": "_bf16", "split": "_split", "x3": "_x3"}[dtype]
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", f"{workload}{tag}_stream_gemm_pmc_summary.json"))):
         try:
             d = json.load(open(f))
@@ -259,7 +267,8 @@ def main():
         return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen)
 
     DTYPE_LABEL = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate",
-                   "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)"}
+                   "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)",
+                   "x3": "f32 X in HBM, products from exact bf16 planes (6 bf16 MFMAs per fragment pair), f32 accumulate"}
 
     def roofline(m: dict) -> dict:
         dtype, info = m["dtype"], m["info"]
@@ -267,12 +276,13 @@ def main():
         launches = m["n_a"] + m["n_b"]
         avg_ms = (m["ms_a"] + m["ms_b"]) / max(1, launches)
         flops_per_launch = 2.0 * G * n_loc * K                    # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
-        bytes_per_launch = (4.0 if mf else 2.0) * G * n_loc       # X read once per sweep (counts: ONE bf16 plane in split mode)
+        bytes_per_launch = (4.0 if dtype in ("f32", "x3") else 2.0) * G * n_loc   # X read once per sweep (counts: ONE bf16 plane in split mode)
         ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         tr = pmc_traffic(args.workload, world, info.k_padded, dtype) if not (args.cells or args.genes) else None
         return {
             "kernel": ("stream_gemm_kernel (MFMA f32 32x32x2; XH^T and W^TX sweeps)" if mf else
+                       "stream_gemm_x3_kernel (float32 X split into exact bf16 planes in registers, MFMA bf16 32x32x16; XH^T and W^TX sweeps)" if dtype == "x3" else
                        "stream_gemm_bf16_kernel (MFMA bf16 32x32x16, k-packed X; XH^T and W^TX sweeps)" +
                        (" with exact plane split" if dtype == "split" else "")),
             "bound": "mfma" if mf else "hbm",
@@ -293,7 +303,7 @@ def main():
     if world == 1 and not args.no_other_modes and not args.no_loss:
         # the same workload in the other storage modes (not the headline): exact bf16-plane split (float32-grade
         # results, applies because the synthetic counts are bf16-exact) and rounded bf16 operands (BASELINE config 5)
-        for dt_name in ("split", "bf16", "f32"):
+        for dt_name in ("x3", "split", "bf16", "f32"):
             if dt_name == args.dtype:
                 continue
             try:

@@ -62,7 +62,12 @@ enum {
      * are exact in float32 and accumulate in float32, so results agree with the float32 path to rounding -- at HBM-bound
      * instead of fp32-MFMA-bound speed.  alpine_finalize_X fails with ALPINE_ERR_UNSUPPORTED if some element of X is not
      * exactly representable by two bf16 planes (then use the float32 layout).  X chunks start at multiples of 8 cells. */
-    ALPINE_FLAG_X_SPLIT = 8
+    ALPINE_FLAG_X_SPLIT = 8,
+    /* float32 X in HBM (layout, ingest and memory exactly as without any storage flag), but the two sweeps form every
+     * product x*p from the exact bf16 planes of x and p on the bf16 matrix pipe: the six plane products that carry
+     * everything above 2^-24 |x p| are accumulated in float32 (kernels_x3.hpp).  No precondition on X; results agree
+     * with the float32-MFMA sweeps to float32 rounding.  Takes effect for K <= 64 (wider models keep the float32 MFMA). */
+    ALPINE_FLAG_X3_PRODUCTS = 16
 };
 enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
 

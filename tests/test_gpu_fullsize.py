@@ -126,6 +126,7 @@ def test_metric_shape_cfg3_checksum_and_loss():
     from alpine_amd import _native
     from alpine_amd.datasets import synth_counts_device_chunks
     from alpine_amd.model import draw_initial_factors
+    from _golden import rel_fro
     dev = torch.device("cuda", 0)
     Gc, Nc, ku, kc = 20000, 200000, 50, [5, 5]
     K = ku + sum(kc)
@@ -138,7 +139,7 @@ def test_metric_shape_cfg3_checksum_and_loss():
         Y[lab, np.arange(Nc)] = 1.0
         Ys.append(Y)
     results = {}
-    for dt in ("f32", "bf16"):
+    for dt in ("f32", "x3", "bf16"):
         eng = _native.NativeShard(n_genes=Gc, n_cells=Nc, n_components=ku, cov_components=kc, cov_levels=[2, 2], lam=[1e3, 1e3],
                                   alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5, x_dtype=dt)
         rowsum = torch.zeros(Gc, dtype=torch.float64, device=dev)
@@ -167,13 +168,15 @@ def test_metric_shape_cfg3_checksum_and_loss():
         losses = eng.losses()
         W, H, _ = eng.get_factors()
         assert np.isfinite(losses).all() and (W >= 0).all() and (H >= 0).all()
-        if dt == "f32":
+        if dt in ("f32", "x3"):
             direct = eng.eval_recon_direct()
             assert abs(losses[-1, 1] - direct) <= 2e-5 * direct
         results[dt] = (losses, W, H)
         eng.close()
         torch.cuda.empty_cache()
+    lx = results["x3"][0]
+    assert np.max(np.abs(lx - results["f32"][0]) / np.abs(results["f32"][0])) < 5e-5     # x3: float32-grade loss rows
+    assert rel_fro(results["x3"][2], results["f32"][2]) < 1e-4 and rel_fro(results["x3"][1], results["f32"][1]) < 1e-4
     lf, lb = results["f32"][0], results["bf16"][0]
     assert np.max(np.abs(lb[:, 1] - lf[:, 1]) / lf[:, 1]) < 1e-3            # bf16 operands: loss rows within 1e-3
-    from _golden import rel_fro
     assert rel_fro(results["bf16"][2], results["f32"][2]) < 2e-2

@@ -18,8 +18,9 @@ def test_cfg4_whole_on_one_gpu():
     spec = importlib.util.spec_from_file_location("huge_check", Path(__file__).resolve().parent.parent / "tools" / "huge_check.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    rep = mod.main(["--modes", "split,f32", "--iters", "4"])
+    rep = mod.main(["--modes", "split,x3,f32", "--iters", "4"])
     assert rep["elements"] > 2 ** 32
     assert rep["modes"]["split"]["xht_exact"] and rep["modes"]["f32"]["xht_exact"]
-    assert rep["split_vs_f32_loss_rows_max_rel"] < 5e-5
+    assert rep["split_vs_f32_loss_rows_max_rel"] < 5e-5 and rep["x3_vs_f32_loss_rows_max_rel"] < 5e-5
+    assert rep["modes"]["x3"]["xht_exact"]
     assert rep["modes"]["split"]["device_GiB"] < 0.55 * rep["modes"]["f32"]["device_GiB"]     # unused second plane was freed

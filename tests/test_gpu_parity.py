@@ -97,10 +97,13 @@ def test_reduce_block_matches_numpy(name):
     eng.close()
 
 
+# x_dtype "x3": float32 X, every product formed from exact bf16 planes on the bf16 matrix pipe (kernels_x3.hpp; takes
+# effect for K <= 64, wider cases run the float32 MFMA) -- held to the SAME tolerances against the reference.
+@pytest.mark.parametrize("x_dtype", ["f32", "x3"])
 @pytest.mark.parametrize("name", SMALL_CASES)
-def test_single_step_vs_reference(name):
+def test_single_step_vs_reference(name, x_dtype):
     c = load_case(name)
-    eng = make_engine(c)
+    eng = make_engine(c, x_dtype=x_dtype)
     eng.run(1, with_loss=False)
     W, H, Bs = eng.get_factors()
     assert rel_fro(W, c.W1) < 1e-5
@@ -110,11 +113,12 @@ def test_single_step_vs_reference(name):
     eng.close()
 
 
+@pytest.mark.parametrize("x_dtype", ["f32", "x3"])
 @pytest.mark.parametrize("name", ALL_CASES)
-def test_full_fit_vs_reference(name):
+def test_full_fit_vs_reference(name, x_dtype):
     c = load_case(name)
     assert c.x_ok
-    eng = make_engine(c)
+    eng = make_engine(c, x_dtype=x_dtype)
     eng.run(c.T, with_loss=True)
     W, H, Bs = eng.get_factors()
     assert rel_fro(W, c.WT_unscaled) < 1e-4
@@ -484,6 +488,46 @@ def test_fit_without_max_iter_runs_warmup_and_elbow():
     assert_loss_rows_close(model.loss_history.to_numpy()[:n], c.loss_history[:n], n_cells=c.X.shape[0])
 
 
+# ------------------------------------------------------------------ float32 X, products from exact bf16 planes (x3)
+@pytest.mark.parametrize("name", ["kl_1cov", "kl_2cov_nan", "ragged", "cfg1"])
+def test_x3_sweep_is_as_accurate_as_float32_mfma(name, record_property):
+    """XH^T of the first iteration against float64: the x3 sweep (six exact plane products, float32 accumulate) must be
+    at least as close to the float64 result as the float32-MFMA sweep is (it drops only terms below 2^-24 of a product)."""
+    nat = _native()
+    c = load_case(name)
+    K = c.W0.shape[1]
+    want = c.X.T.astype(np.float64) @ c.H0.T.astype(np.float64)               # G x K
+    err = {}
+    for dt in ("f32", "x3"):
+        eng = make_engine(c, x_dtype=dt)
+        eng.iter_begin()
+        info = eng.info()
+        KP = info.k_padded
+        XHt = eng.read_buffer(nat.BUF_REDUCE_BLOCK, 0, info.genes_padded * KP).reshape(info.genes_padded, KP)[:c.X.shape[1], :K]
+        err[dt] = float(np.linalg.norm(XHt - want) / np.linalg.norm(want))
+        eng.close()
+    record_property("xht_rel_err_vs_f64", err)
+    assert err["x3"] < 1e-6 and err["x3"] <= 1.5 * err["f32"] + 1e-8, err
+
+
+def test_x3_arbitrary_float32_values():
+    """No precondition on X: values spanning 12 orders of magnitude with full 24-bit significands."""
+    c = load_case("kl_2cov_nan")
+    rng = np.random.default_rng(5)
+    c.X = (c.X * np.exp(rng.uniform(-14, 14, size=c.X.shape))).astype(np.float32)
+    a = make_engine(c)
+    b = make_engine(c, x_dtype="x3")
+    a.run(3, with_loss=True)
+    b.run(3, with_loss=True)
+    Wa, Ha, _ = a.get_factors()
+    Wb, Hb, _ = b.get_factors()
+    assert np.isfinite(Wb).all() and np.isfinite(Hb).all()
+    assert rel_fro(Wb, Wa) < 1e-5 and rel_fro(Hb, Ha) < 1e-5
+    assert_loss_rows_close(b.losses(), a.losses(), n_cells=c.X.shape[0])
+    a.close()
+    b.close()
+
+
 # ------------------------------------------------------------------ exact-split storage on the bf16 matrix pipe
 def _count_like(c, scale):
     """Integer-valued X from a golden case's matrix: scale=40 -> < 256 mostly? no: forces the range we want below."""
@@ -548,7 +592,7 @@ def test_split_refuses_inexact_X_and_auto_falls_back():
     eng.close()
     from alpine_amd import ALPINE, MiniAnnData
     m = ALPINE(device="cuda", x_dtype="auto", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
-    assert m.x_dtype_used == "f32"
+    assert m.x_dtype_used == "x3"
     assert rel_fro(np.concatenate(m.matrices["Hs"], axis=0), c.HT) < 1e-4
     with pytest.raises(nat.AlpineNativeError):
         ALPINE(device="cuda", x_dtype="split", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=2)

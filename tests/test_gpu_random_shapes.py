@@ -1,6 +1,6 @@
 """Randomised shapes through the C ABI against the CPU oracle (fused form = the kernels' numerical spec): ragged G / N
 (not multiples of any tile), K from 1 to ~100, 0-2 covariates with 1-4 levels, both loss types, regularisers on/off,
-several stream-K span sizes, float32 and (on integer data) the exact-split path.  Two MU steps + loss rows each."""
+several stream-K span sizes; float32 MFMA, the x3 plane-product sweeps and (on integer data) the exact-split path.  Two MU steps + loss rows each."""
 import numpy as np
 import pytest
 import torch
@@ -46,7 +46,7 @@ def test_random_shape_two_steps_vs_oracle(seed):
     s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
     W0, H0, B0 = s.W.numpy().copy(), s.H.numpy().copy(), [b.numpy().copy() for b in s.Bs]
     orc.fit_fused(p, s, 2, with_loss=True)
-    modes = ["f32"] + (["split"] if integer and float(X.max()) < 65536 else [])
+    modes = ["f32", "x3"] + (["split"] if integer and float(X.max()) < 65536 else [])
     for mode in modes:
         eng = nat.NativeShard(n_genes=X.shape[1], n_cells=X.shape[0], n_components=p.n_components,
                               cov_components=p.n_covariate_components, cov_levels=[y.shape[1] for y in Ys], lam=p.lam,
@@ -99,25 +99,26 @@ def test_random_shape_als_and_minibatch_vs_oracle(seed):
             for idx in epoch:
                 step(p, s, torch.tensor(idx, dtype=torch.long))
             s.losses.append(orc.loss_row(p, s))
-    eng = nat.NativeShard(n_genes=X.shape[1], n_cells=N, n_components=p.n_components, cov_components=p.n_covariate_components,
-                          cov_levels=[y.shape[1] for y in Ys], lam=p.lam, orth_W=p.orth_W, alpha_W=p.alpha_W,
-                          l1_ratio_W=p.l1_ratio_W, eps=p.eps, loss_type=p.loss_type, use_als=use_als, batch_capacity=bs)
-    eng.upload_X_host(X)
-    eng.finalize_X()
-    for i, y in enumerate(Ys):
-        eng.upload_Y(i, np.ascontiguousarray(y.T))
-    eng.set_factors(W0, H0, B0)
-    for epoch in batches:
-        for idx in epoch:
-            eng.batch_step(idx)
-        eng.epoch_loss()
-    W, H, Bs = eng.get_factors()
-    losses = eng.losses()
-    eng.close()
-    tag = f"seed {seed} als={use_als} G={X.shape[1]} N={N} bs={bs} K={p.total_components} cov={p.n_covariate_components} {p.loss_type}"
-    assert rel_fro(W, s.W.numpy()) < 5e-5, tag
-    assert rel_fro(H, s.H.numpy()) < 5e-5, tag
-    for b, bo in zip(Bs, s.Bs):
-        assert rel_fro(b, bo.numpy()) < 1e-4, tag
-    want = np.array(s.losses)
-    np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=1e-4, err_msg=tag)
+    for mode in ("f32", "x3"):
+        eng = nat.NativeShard(n_genes=X.shape[1], n_cells=N, n_components=p.n_components, cov_components=p.n_covariate_components,
+                              cov_levels=[y.shape[1] for y in Ys], lam=p.lam, orth_W=p.orth_W, alpha_W=p.alpha_W,
+                              l1_ratio_W=p.l1_ratio_W, eps=p.eps, loss_type=p.loss_type, use_als=use_als, batch_capacity=bs, x_dtype=mode)
+        eng.upload_X_host(X)
+        eng.finalize_X()
+        for i, y in enumerate(Ys):
+            eng.upload_Y(i, np.ascontiguousarray(y.T))
+        eng.set_factors(W0, H0, B0)
+        for epoch in batches:
+            for idx in epoch:
+                eng.batch_step(idx)
+            eng.epoch_loss()
+        W, H, Bs = eng.get_factors()
+        losses = eng.losses()
+        eng.close()
+        tag = f"seed {seed} mode {mode} als={use_als} G={X.shape[1]} N={N} bs={bs} K={p.total_components} cov={p.n_covariate_components} {p.loss_type}"
+        assert rel_fro(W, s.W.numpy()) < 5e-5, tag
+        assert rel_fro(H, s.H.numpy()) < 5e-5, tag
+        for b, bo in zip(Bs, s.Bs):
+            assert rel_fro(b, bo.numpy()) < 1e-4, tag
+        want = np.array(s.losses)
+        np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=1e-4, err_msg=tag)

@@ -26,7 +26,7 @@ def main(argv=None):
     ap.add_argument("--cells", type=int, default=1_000_000)
     ap.add_argument("--genes", type=int, default=20_000)
     ap.add_argument("--ku", type=int, default=100)
-    ap.add_argument("--modes", default="split,f32")
+    ap.add_argument("--modes", default="split,x3,f32")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--out", default="")
     args = ap.parse_args(argv)
@@ -90,7 +90,7 @@ def main(argv=None):
                 assert np.isfinite(losses).all() and (W >= 0).all() and (H >= 0).all() and np.isfinite(H).all()
                 assert (np.diff(losses[:, 1]) < 0).all(), losses[:, 1]
                 res["recon_loss"] = [float(v) for v in losses[:, 1]]
-                if mode == "f32":
+                if mode in ("f32", "x3"):
                     direct = eng.eval_recon_direct()
                     res["direct_vs_trace_rel"] = abs(losses[-1, 1] - direct) / direct
                     assert res["direct_vs_trace_rel"] < 2e-5, res
@@ -115,10 +115,11 @@ def main(argv=None):
         res["wall_s"] = time.time() - t0
         report["modes"][mode] = res
         print(mode, json.dumps(res), flush=True)
-    if "f32" in loss_rows and "split" in loss_rows:
-        d = np.max(np.abs(loss_rows["split"] - loss_rows["f32"]) / np.abs(loss_rows["f32"]))
-        report["split_vs_f32_loss_rows_max_rel"] = float(d)
-        assert d < 5e-5, d
+    for other in ("split", "x3"):
+        if "f32" in loss_rows and other in loss_rows:
+            d = np.max(np.abs(loss_rows[other] - loss_rows["f32"]) / np.abs(loss_rows["f32"]))
+            report[f"{other}_vs_f32_loss_rows_max_rel"] = float(d)
+            assert d < 5e-5, d
     print(json.dumps(report))
     if args.out:
         Path(args.out).write_text(json.dumps(report, indent=1))
