@@ -49,8 +49,7 @@ struct alpine_ctx {
     int64_t x_plane_gn = 0, x_plane_ng = 0;                  // element offsets plane 2 - plane 1 of the two copies
     bool bf16 = false;                // any bf16-pipe mode (rounded operands or exact split)
     bool split = false;               // exact-split mode
-    int npx = 1, npp = 1;             // bf16 planes of X / of the panels
-    int64_t x_plane = 0;              // elements between the planes of an X copy
+    int npx = 1;                      // bf16 planes of X in use (split mode: 1 or 2)
     int* xflags = nullptr;            // device: [0] some element of X not exact in the stored planes, [1] second plane in use
     float *piecesA = nullptr, *piecesB = nullptr;     // stream-K partial results of the two sweeps
     SweepGeom geomA{}, geomB{};
@@ -227,7 +226,6 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->split = (cfg->flags & ALPINE_FLAG_X_SPLIT) != 0;
     c->bf16 = (cfg->flags & ALPINE_FLAG_X_BF16) != 0 || c->split;
     c->npx = c->split ? 2 : 1;        // two planes until alpine_finalize_X knows whether the second is needed
-    c->npp = c->split ? 3 : 1;
     c->use_als = (cfg->flags & ALPINE_FLAG_USE_ALS) != 0;
     c->x3 = (cfg->flags & ALPINE_FLAG_X3_PRODUCTS) != 0 && !c->bf16;
     c->device = cfg->device_id;
@@ -274,7 +272,6 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->Xgn, float, c->bf16 ? 4 : Gp * Np);
     ALLOC(c, c->Xng, float, (c->transform_only || c->bf16) ? 4 : Np * Gp);
     if (c->bf16) {
-        c->x_plane = Gp * Np;
         ALLOC(c, c->Xgn16, unsigned short, Gp * Np);
         ALLOC(c, c->Xng16, unsigned short, c->transform_only ? 8 : Np * Gp);
         if (c->split) {                                      // second plane in its own allocation so that it can be dropped
@@ -283,8 +280,9 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
             c->x_plane_gn = c->Xgn16b - c->Xgn16;
             c->x_plane_ng = c->Xng16b - c->Xng16;
         }
-        ALLOC(c, c->Wp16, unsigned short, c->npp * Gp * KP);
-        ALLOC(c, c->Hp16, unsigned short, c->npp * Np * KP);
+        // rounded mode: bf16 operand copies of the panels (the split forms read the float32 masters)
+        ALLOC(c, c->Wp16, unsigned short, c->split ? 8 : Gp * KP);
+        ALLOC(c, c->Hp16, unsigned short, c->split ? 8 : Np * KP);
         ALLOC(c, c->xflags, int, 4);
     }
     ALLOC(c, c->W, float, Gp * KP);

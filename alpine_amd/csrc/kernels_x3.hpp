@@ -26,16 +26,25 @@ namespace alpine {
 constexpr int X3_RING = 2;                  // k-steps in the X ring
 constexpr int X3_ROWS = 16 * X3_RING;       // rows per panel stage
 
-// exact planes of 8 consecutive rows of one column, packed as MFMA B operands (8 bf16 = 4 dwords per plane)
+// exact planes of 8 consecutive rows of one column, packed as MFMA B operands (8 bf16 = 4 dwords per plane).  Works on
+// PAIRS so that every conversion is one v_cvt_pk_bf16_f32 whose result already is the packed operand dword (even row
+// in the low half): per pair 3 conversions + 4 bit operations + 2 packed subtractions.  Same values as f32_split3.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x3_cvt_pk(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v)); }
+__device__ __forceinline__ f32x2 x3_unpack(unsigned p) { return f32x2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }
+
 __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 (&b)[3])
 {
-    unsigned short pl[3][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f32_split3(v[e], pl[0][e], pl[1][e], pl[2][e]);
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-        b[q] = u32x4{(unsigned)pl[q][0] | ((unsigned)pl[q][1] << 16), (unsigned)pl[q][2] | ((unsigned)pl[q][3] << 16),
-                     (unsigned)pl[q][4] | ((unsigned)pl[q][5] << 16), (unsigned)pl[q][6] | ((unsigned)pl[q][7] << 16)};
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 x = {v[2 * q], v[2 * q + 1]};
+        const unsigned hi = x3_cvt_pk(x);
+        const f32x2 r1 = x - x3_unpack(hi);
+        const unsigned mid = x3_cvt_pk(r1);
+        const f32x2 r2 = r1 - x3_unpack(mid);
+        b[0][q] = hi; b[1][q] = mid; b[2][q] = x3_cvt_pk(r2);
+    }
 }
 
 // One panel stage = X3_RING k-steps.  Per k-step: A fragments of all three panel planes (double-buffered over k-steps),
