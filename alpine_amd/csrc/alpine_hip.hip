@@ -1008,14 +1008,23 @@ extern "C" int alpine_eval_recon_direct(alpine_ctx* c, double* out)
 {
     int rc = ready(c);
     if (rc) return rc;
-    if (c->bf16 || c->transform_only) return fail(c, ALPINE_ERR_UNSUPPORTED, "direct evaluation needs the float32 cells x genes copy of X");
+    if (c->bf16) return fail(c, ALPINE_ERR_UNSUPPORTED, "direct evaluation needs a float32 copy of X");
     if (!out) return fail(c, ALPINE_ERR_BAD_ARG, "out is NULL");
-    const int gx = (c->G + 255) / 256;
+    // sum_n sum_g (X[n][g] - sum_k W[g][k] H[n][k])^2 is symmetric in (genes, W) <-> (cells, H): a transform-only ctx
+    // keeps only the genes x cells copy and evaluates the same kernel with the roles swapped
+    const bool swap = c->transform_only;
+    const int A = swap ? c->N : c->G, Bn = swap ? c->G : c->N;       // A: thread axis (contiguous in X), Bn: looped axis
+    const int gx = (A + 255) / 256;
     int cells_per_block = 256;
-    while ((int64_t)gx * ((c->N + cells_per_block - 1) / cells_per_block) > c->f64part_n) cells_per_block *= 2;
-    const int gy = (c->N + cells_per_block - 1) / cells_per_block;
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(eval_recon_kernel<KT_>, dim3(gx, gy), dim3(256), 0, c->stream, c->Xng, c->Gp, c->W, c->H,
-                                           c->G, c->N, cells_per_block, c->f64part));
+    while ((int64_t)gx * ((Bn + cells_per_block - 1) / cells_per_block) > c->f64part_n) cells_per_block *= 2;
+    const int gy = (Bn + cells_per_block - 1) / cells_per_block;
+    if (swap) {
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(eval_recon_kernel<KT_>, dim3(gx, gy), dim3(256), 0, c->stream, c->Xgn, c->Np, c->H, c->W,
+                                               A, Bn, cells_per_block, c->f64part));
+    } else {
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(eval_recon_kernel<KT_>, dim3(gx, gy), dim3(256), 0, c->stream, c->Xng, c->Gp, c->W, c->H,
+                                               A, Bn, cells_per_block, c->f64part));
+    }
     HIPCHK(c, hipGetLastError());
     return sum_f64_partials(c, gx * gy, out);
 }

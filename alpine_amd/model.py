@@ -394,6 +394,73 @@ class ALPINE:
             adata.obsm[f"{covariate}_dummy_matrix"] = dummy_matrices[i]
             adata.varm[covariate] = copy(self.matrices["Ws"][i])
 
+    # ------------------------------------------------------ post-fit helpers (main.py:187-273)
+    def compute_loss(self, adata):
+        """main.py:187-236: total loss of the factors stored in ``adata`` (after fit or transform).  The G x N term
+        ||X - W H||_F^2 is evaluated on the device (float64 accumulation, no G x N temporary); the prediction terms are
+        C_i x N and follow the reference's numpy expressions."""
+        if not hasattr(self, "matrices"):
+            raise RuntimeError("Model is not trained yet. Please fit the model first.")
+        if not is_anndata(adata):
+            raise TypeError("adata must be an AnnData object.")
+        if "ALPINE_embedding" not in adata.obsm:
+            raise ValueError("ALPINE_embedding not found in adata.obsm. Please transform the data first.")
+        Hs = [np.asarray(adata.obsm[k], dtype=np.float32).T for k in self.covariate_keys] + \
+             [np.asarray(adata.obsm["ALPINE_embedding"], dtype=np.float32).T]
+        Ws = [np.asarray(adata.varm[k], dtype=np.float32) for k in self.covariate_keys] + \
+             [np.asarray(adata.varm["ALPINE_weights"], dtype=np.float32)]
+        W = np.ascontiguousarray(np.concatenate(Ws, axis=1))
+        H = np.ascontiguousarray(np.concatenate(Hs, axis=0))
+        recon_loss = self._recon_loss_device(np.asarray(adata.X), W, H)
+
+        def kl_divergence(y, y_hat):                                                   # main.py:200-204
+            y_hat = np.clip(y_hat, a_min=self.eps, a_max=None)
+            return np.sum(y * np.log(np.clip(y / y_hat, a_min=self.eps, a_max=None)) - y + y_hat)
+
+        Ys = self.fe.transform(adata.obs)
+        Bs = self.matrices["Bs"]
+        if self.loss_type == "kl-divergence":
+            pred_loss = [kl_divergence(Ys[i].T, Bs[i] @ Hs[i]) for i in range(len(Ys))]
+        else:
+            pred_loss = [np.linalg.norm(Ys[i].T - Bs[i] @ Hs[i], ord="fro") ** 2 for i in range(len(Ys))]
+        return recon_loss + sum(self.lam[i] * pl for i, pl in enumerate(pred_loss))
+
+    def _recon_loss_device(self, X_cells_genes: np.ndarray, W: np.ndarray, H: np.ndarray) -> float:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: alpine_amd needs an MI355X (there is no CPU fallback)")
+        dev_index = _parse_device(str(self.device))
+        if dev_index < 0:
+            dev_index = torch.cuda.current_device()
+        n_sample, G = X_cells_genes.shape
+        eng = _native.NativeShard(n_genes=G, n_cells=n_sample, n_components=W.shape[1], cov_components=[], cov_levels=[], lam=[],
+                                  eps=self.eps, device_id=dev_index, transform_only=True, x_dtype="f32")
+        try:
+            chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)
+            for r0 in range(0, n_sample, chunk):
+                eng.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r0 + chunk], dtype=np.float32), _native.X_CELLS_BY_GENES, r0)
+            eng.finalize_X()
+            eng.set_factors(W, H, [])
+            return float(eng.eval_recon_direct())
+        finally:
+            eng.close()
+
+    def get_covariate_gene_scores(self, adata=None):
+        """main.py:246-273: per covariate, W_i (H_i Y_i^T / rowsum(Y_i)) as a genes x levels DataFrame (G x k_i x C_i work)."""
+        if not hasattr(self, "matrices"):
+            raise RuntimeError("Model is not trained yet. Please fit the model first.")
+        cov_gene_scores = {}
+        for i, covariate in enumerate(self.covariate_keys):
+            W = self.matrices["Ws"][i]
+            H = self.matrices["Hs"][i]
+            Y = self.matrices["Ys"][i]
+            HY = H @ Y.T / Y.sum(axis=1)
+            cov_gene_scores[covariate] = pd.DataFrame(W @ HY, index=self.feature_names, columns=self.fe.encoded_labels[covariate])
+        if adata is None:
+            return cov_gene_scores
+        for condition, df in cov_gene_scores.items():
+            adata.varm[condition + "_gene_scores"] = df
+        return None
+
     def get_decomposed_matrices(self):
         """main.py:238-244."""
         if not hasattr(self, "matrices"):

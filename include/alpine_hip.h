@@ -175,8 +175,9 @@ int alpine_scale(alpine_ctx* ctx);
 
 int alpine_synchronize(alpine_ctx* ctx);
 
-/* Validation helper ("common evaluator"): direct-form ||X_local - W H_local||_F^2 with
- * float64 accumulation.  Synchronises. */
+/* Direct-form ||X_local - W H_local||_F^2 of the CURRENT factors with float64 accumulation: the "common evaluator" of
+ * SURVEY.md section 7, and the G x N part of ALPINE.compute_loss (main.py:216-219: np.linalg.norm(X - W @ H)**2).
+ * Needs float32 storage of X (any ctx but the bf16 / split ones; a transform-only ctx works).  Synchronises. */
 int alpine_eval_recon_direct(alpine_ctx* ctx, double* out);
 
 /* Measurement: when enabled, hipEvents bracket every launch of the two streaming sweeps. */

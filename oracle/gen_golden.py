@@ -225,10 +225,45 @@ def run_case(case: dict, AnnData, out_dir: str):
           f"loss[-1]={out['loss_history'][-1].tolist()}")
 
 
+POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov"]
+
+
+def run_posthoc(case: dict, AnnData, out_dir: str):
+    """Post-fit helpers of the reference on the fitted model: compute_loss(adata) on the training
+    cells (main.py:187-236) and, where the case has a transform, on the transformed cells; get_covariate_gene_scores()
+    (main.py:246-273).  Written to a separate fixture so that the fit fixtures stay byte-identical."""
+    import alpine  # the reference
+    X, obs = make_case_inputs(case)
+    keys = [c[0] for c in case["covariates"]]
+    a = AnnData(X.copy(), obs.copy())
+    m = alpine.ALPINE(device="cpu", **case["params"])
+    m.fit(a, covariate_keys=keys, max_iter=case["T"], **case.get("fit_kwargs", {}))
+    out = {"compute_loss_fit": np.float64(m.compute_loss(a))}
+    scores = m.get_covariate_gene_scores()
+    for k in keys:
+        out[f"gene_scores_{k}"] = scores[k].to_numpy(dtype=np.float64)
+    cols = {k: [str(c) for c in scores[k].columns] for k in keys}
+    a2 = AnnData(X.copy(), obs.copy())
+    assert m.get_covariate_gene_scores(a2) is None
+    varm_keys = sorted(a2.varm)
+    if case.get("transform_iters"):
+        n_t = (2 * case["n_cells"]) // 3
+        a_t = AnnData(X[:n_t].copy(), obs.iloc[:n_t].copy())
+        m.transform(a_t, n_iter=case["transform_iters"])
+        out["compute_loss_transform"] = np.float64(m.compute_loss(a_t))
+    out["meta_json"] = np.array(json.dumps(dict(name=case["name"], gene_score_columns=cols, gene_score_varm_keys=varm_keys,
+                                                generator="oracle/gen_golden.py --posthoc running /root/reference (ALPINE v0.2.0) on torch-CPU")))
+    path = os.path.join(out_dir, f"posthoc_{case['name']}.npz")
+    np.savez_compressed(path, **out)
+    print(f"posthoc {case['name']:>14}: compute_loss={float(out['compute_loss_fit']):.9g} "
+          f"{'transform=' + format(float(out['compute_loss_transform']), '.9g') if 'compute_loss_transform' in out else ''}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--posthoc", action="store_true", help="write only the posthoc_<case>.npz fixtures")
     args = ap.parse_args()
     if not os.path.isdir(REFERENCE):
         sys.exit("the reference is not present here; golden vectors can only be regenerated in the build container")
@@ -237,7 +272,11 @@ def main():
     for case in CASES:
         if args.only and case["name"] not in args.only:
             continue
-        run_case(case, AnnData, args.out)
+        if args.posthoc:
+            if case["name"] in POSTHOC_CASES:
+                run_posthoc(case, AnnData, args.out)
+        else:
+            run_case(case, AnnData, args.out)
 
 
 if __name__ == "__main__":

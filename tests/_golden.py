@@ -59,6 +59,19 @@ def load_case(name: str) -> SimpleNamespace:
     return c
 
 
+POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov"]
+
+
+def load_posthoc(name: str) -> SimpleNamespace:
+    """compute_loss / get_covariate_gene_scores outputs of the reference on the fitted model (oracle/gen_golden.py --posthoc)."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"posthoc_{name}.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta_json"]))
+    return SimpleNamespace(compute_loss_fit=float(z["compute_loss_fit"]),
+                           compute_loss_transform=float(z["compute_loss_transform"]) if "compute_loss_transform" in z.files else None,
+                           gene_scores={k: z[f"gene_scores_{k}"] for k in meta["gene_score_columns"]},
+                           gene_score_columns=meta["gene_score_columns"], varm_keys=meta["gene_score_varm_keys"])
+
+
 def rel_fro(a, b) -> float:
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

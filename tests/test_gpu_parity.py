@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import ALL_CASES, ALS_CASES, BATCH_CASES, SMALL_CASES, assert_loss_rows_close, load_case, rel_fro
+from _golden import (ALL_CASES, ALS_CASES, BATCH_CASES, POSTHOC_CASES, SMALL_CASES, assert_loss_rows_close, load_case, load_posthoc,
+                     rel_fro)
 
 pytestmark = pytest.mark.gpu
 
@@ -255,6 +256,34 @@ def test_drop_in_api_end_to_end():
     assert {k: list(np.asarray(v).shape) for k, v in adata.obsm.items()} == c.meta["obsm_shapes"]
     assert {k: list(np.asarray(v).shape) for k, v in adata.varm.items()} == c.meta["varm_shapes"]
     assert all(np.asarray(v).dtype == np.float32 for v in adata.obsm.values())
+
+
+@pytest.mark.parametrize("name", POSTHOC_CASES)
+def test_compute_loss_and_gene_scores_vs_reference(name):
+    """Post-fit helpers (main.py:187-273) through the drop-in class against the reference's values for the same fit:
+    compute_loss on the training cells, on transformed cells, and the covariate gene scores."""
+    from alpine_amd import ALPINE, MiniAnnData
+    c, ph = load_case(name), load_posthoc(name)
+    adata = MiniAnnData(c.X.copy(), c.obs.copy())
+    m = ALPINE(device="cuda", **c.params)
+    with pytest.raises(RuntimeError, match="Model is not trained yet"):
+        m.compute_loss(adata)
+    m.fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+    got = m.compute_loss(adata)
+    assert abs(got - ph.compute_loss_fit) <= 1e-4 * ph.compute_loss_fit, (got, ph.compute_loss_fit)
+    # the same number from the fit's own last loss row computed on the UNSCALED factors (scaling leaves W H and B H unchanged)
+    assert abs(got - m.loss_history.iloc[-1, 0]) <= 1e-4 * got
+    with pytest.raises(ValueError, match="ALPINE_embedding not found"):
+        m.compute_loss(MiniAnnData(c.X.copy(), c.obs.copy()))
+    scores = m.get_covariate_gene_scores()
+    for k in c.keys:
+        assert rel_fro(scores[k].to_numpy(), ph.gene_scores[k]) < 2e-4
+    if ph.compute_loss_transform is not None:
+        n_t = (2 * c.X.shape[0]) // 3
+        a_t = MiniAnnData(c.X[:n_t].copy(), c.obs.iloc[:n_t].copy())
+        m.transform(a_t, n_iter=c.transform_iters)
+        got_t = m.compute_loss(a_t)
+        assert abs(got_t - ph.compute_loss_transform) <= 2e-4 * ph.compute_loss_transform, (got_t, ph.compute_loss_transform)
 
 
 def test_native_library_is_what_ran():

@@ -7,7 +7,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from _golden import ALL_CASES, SMALL_CASES, load_case
+from _golden import ALL_CASES, POSTHOC_CASES, SMALL_CASES, load_case, load_posthoc
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -204,3 +204,30 @@ def test_kneedle_restatement_invariants():
     assert find_elbow(t, 3.0 * y + 7.0) == e                    # affine changes of y do not move the elbow
     assert find_elbow(10.0 * t + 5.0, y) == 10.0 * e + 5.0      # nor do affine changes of x (returned in x units)
     assert find_elbow(t[:2], y[:2]) is None
+
+
+@pytest.mark.parametrize("name", POSTHOC_CASES)
+def test_covariate_gene_scores_match_reference(name):
+    """get_covariate_gene_scores (main.py:246-273) on the reference's own final factors: same frames, same varm keys."""
+    from alpine_amd import ALPINE, MiniAnnData
+    from alpine_amd.encoder import FeatureEncoders
+    c, ph = load_case(name), load_posthoc(name)
+    m = ALPINE(device="cuda", **c.params)
+    with pytest.raises(RuntimeError, match="Model is not trained yet"):
+        m.get_covariate_gene_scores()
+    m.covariate_keys = c.keys
+    m.fe = FeatureEncoders(c.keys)
+    m.fe.fit_transform(c.obs)
+    m.feature_names = [f"gene{i}" for i in range(c.X.shape[1])]
+    offs = np.cumsum([0] + m.n_all_components)
+    m.matrices = {"Ws": [c.WT[:, offs[j]:offs[j + 1]] for j in range(len(offs) - 1)],
+                  "Hs": [c.HT[offs[j]:offs[j + 1]] for j in range(len(offs) - 1)], "Ys": c.Ys, "Bs": c.BT}
+    scores = m.get_covariate_gene_scores()
+    assert list(scores) == c.keys
+    for k in c.keys:
+        assert list(scores[k].columns) == ph.gene_score_columns[k]
+        assert list(scores[k].index) == m.feature_names
+        np.testing.assert_allclose(scores[k].to_numpy(), ph.gene_scores[k], rtol=2e-6, atol=1e-12)
+    a = MiniAnnData(c.X.copy(), c.obs.copy())
+    assert m.get_covariate_gene_scores(a) is None
+    assert sorted(a.varm) == ph.varm_keys
