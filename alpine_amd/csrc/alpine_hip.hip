@@ -673,11 +673,13 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     if (c->bf16) return launch_sweep_bf16(c, which, g);
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
     if (c->x3) {
+        SweepGeom gx = g;
+        if (getenv_is("ALPINE_HIP_ABLATE_FLUSH", '1')) gx.panel_fixed = 2;
         switch (c->KT) {
-            case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
-            case 2: hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
-            case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
-            default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, g); break;
+            case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            case 2: hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
         }
         HIPCHK(c, hipGetLastError());
         return 0;

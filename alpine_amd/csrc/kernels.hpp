@@ -125,6 +125,39 @@ __device__ __forceinline__ int64_t sg_piece_offset(const SweepGeom& g, int w, in
     return ((int64_t)w * g.maxp + (ft - first)) * g.bf * KP;
 }
 
+// Flush of one accumulator tile group (KT MFMA tiles = 32 f columns x KP components, C/D layout: lane (c, h) holds
+// k = 32m + 8q + 4h + e of column c) to 32 rows of a piece with FULL-LINE stores.  Written straight from the C/D
+// registers every store instruction scatters 64 x 16 B over 32 rows (32-byte fragments of 128-byte lines); those
+// partial-line writes cost far more than their bytes (an iteration at cfg3 was 5 % faster with the flush ablated).
+// So the tile goes through a wave-private LDS scratch (32 x (KP + 4) floats) and comes back row-major: one store
+// instruction = 64 x 16 contiguous bytes per row group.  Row c of the tile lands at out_row0 + c * row_stride.
+template <int KT>
+__device__ __forceinline__ void sg_flush_tile(float* __restrict__ tr, const f32x16* const (&d)[KT], float* __restrict__ out_row0,
+                                              int64_t row_stride, int lane)
+{
+    constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x16& t = *d[m];
+            *reinterpret_cast<f32x4*>(&tr[c * LD + 32 * m + 8 * q + 4 * h]) = f32x4{t[4 * q + 0], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < (32 * Q4) / 64; ++i) {
+        const int idx = i * 64 + lane, r = idx / Q4, c4 = idx % Q4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&tr[r * LD + 4 * c4]);
+        *reinterpret_cast<f32x4*>(out_row0 + (int64_t)r * row_stride + 4 * c4) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // SG_RING = X register ring depth in MFMA k-steps (= prefetch distance); SG_PASSES = ring passes per panel stage
 // (one barrier per 2*SG_RING*SG_PASSES rows).
 template <int KT, int SG_RING, int SG_PASSES>
@@ -142,6 +175,7 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
     constexpr int PV = SG_CH * KP / 4 / SG_THREADS;                // float4 per thread per panel stage
     static_assert(SG_CH * KP / 4 % SG_THREADS == 0, "panel stage must tile the workgroup exactly");
     __shared__ __attribute__((aligned(16))) float lds[2][SG_CH * KP];
+    __shared__ __attribute__((aligned(16))) float flush_tr[SG_WAVES][32 * (KP + 4)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -248,17 +282,15 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
             sg_stage<KT, SG_RING, true>(acc, x, lb + (SG_PASSES - 1) * PASS * KP, xrow, ldS);
         }
 
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * SG_BLOCK_F + wave * SG_WAVE_F + 4 * c) * KP + 4 * h;
+        // D row (k within tile m) = 8q + 4h + e, D column = lane & 31 = c -> f_local = 128*wave + 4c + j
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * SG_BLOCK_F + wave * SG_WAVE_F) * KP;
 #pragma unroll
-        for (int m = 0; m < KT; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const f32x16* d[KT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v = {acc[m][j][4 * q + 0], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
-                    // D row (k within tile m) = 8q + 4h + e, D column = lane&31 -> f_local = 128*wave + 4c + j
-                    *reinterpret_cast<f32x4*>(out + (int64_t)j * KP + 32 * m + 8 * q) = v;
-                }
+            for (int m = 0; m < KT; ++m) d[m] = &acc[m][j];
+            sg_flush_tile<KT>(flush_tr[wave], d, out + (int64_t)j * KP, 4 * KP, lane);
+        }
     }
     if (clk && tid == 0) {
         clk[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;

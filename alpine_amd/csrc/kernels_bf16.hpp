@@ -246,6 +246,7 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
     constexpr int GRAN = STAGE_BF16 / 8;                            // 16-byte granules per plane per stage
     constexpr int PV = NPP == 1 ? (GRAN + NT - 1) / NT : 1;     // granules per thread per stage (bf16 panel copy)
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][NPP * STAGE_BF16];
+    __shared__ __attribute__((aligned(16))) float flush_tr[NW][32 * (KP + 4)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -379,16 +380,14 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
         bf_stage<KT, NPX, NPP, BF_RING, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = 128*wave + 32*j + c
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * (NW * SG_WAVE_F) + wave * SG_WAVE_F + c) * KP + 4 * h;
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * (NW * SG_WAVE_F) + wave * SG_WAVE_F) * KP;
 #pragma unroll
-        for (int m = 0; m < KT; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const f32x16* d[KT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v = {acc[m][j][4 * q + 0], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(out + (int64_t)(32 * j) * KP + 32 * m + 8 * q) = v;
-                }
+            for (int m = 0; m < KT; ++m) d[m] = &acc[m][j];
+            sg_flush_tile<KT>(flush_tr[wave], d, out + (int64_t)(32 * j) * KP, KP, lane);
+        }
     }
 }
 

@@ -116,6 +116,7 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
     constexpr int SETS = (X3_ROWS / 8) * KP;                        // (8-row block, column) granule positions of one stage
     constexpr int PVS = (SETS + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * STAGE_BF16];
+    __shared__ __attribute__((aligned(16))) float flush_tr[4][32 * (KP + 4)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,20 +227,17 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F + 4 * c) * KP + 4 * h;
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
-            if (hf == 1 && f1 == f0) break;                          // second half outside F: nothing to write
+            if ((hf == 1 && f1 == f0) || g.panel_fixed == 2) break;    // second half outside F: nothing to write (panel_fixed == 2: timing-only ablation of the flush)
 #pragma unroll
-            for (int m = 0; m < KT; ++m)
+            for (int tt = 0; tt < 4; ++tt) {
+                const f32x16* d[KT];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const f32x16& d = acc[m][4 * hf + tt];
-                        f32x4 v = {d[4 * q + 0], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
-                        *reinterpret_cast<f32x4*>(out + (int64_t)(128 * hf + tt) * KP + 32 * m + 8 * q) = v;
-                    }
+                for (int m = 0; m < KT; ++m) d[m] = &acc[m][4 * hf + tt];
+                sg_flush_tile<KT>(flush_tr[wave], d, out + (int64_t)(128 * hf + tt) * KP, 4 * KP, lane);
+            }
         }
     }
 }
