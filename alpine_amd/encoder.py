@@ -30,13 +30,17 @@ class FeatureEncoders:
         out[rows, idx_c[known]] = 1.0
         return out
 
-    def fit_transform(self, df: pd.DataFrame) -> List[np.ndarray]:
+    def fit_transform(self, df: pd.DataFrame, merge_categories=None) -> List[np.ndarray]:
+        """``merge_categories`` (extension for rank-local inputs): a callable that maps this rank's sorted categories
+        of one column to the sorted union over all ranks, so that every rank builds the same one-hot columns."""
         if not isinstance(df, pd.DataFrame):
             raise TypeError("adata.obs must be a pandas DataFrame.")
         mats = []
         for key in self.covariate_keys:
             col = df[key]
             cats = np.unique(col[~col.isna()].to_numpy())          # sorted, like OneHotEncoder(categories="auto")
+            if merge_categories is not None:
+                cats = merge_categories(cats)
             self.categories[key] = cats
             self.encoded_labels[key] = [f"{key}_{c}" for c in cats.tolist()]
             mats.append(self._encode(col, cats))

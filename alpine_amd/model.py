@@ -64,7 +64,7 @@ class ALPINE:
         device: str = "cuda",
         eps: float = 1e-6,
         random_state: int = 42,
-        shard_cells: bool = False,
+        shard_cells: Union[bool, str] = False,
         x_dtype: str = "x3",
     ):
         self.n_components = n_components
@@ -82,8 +82,12 @@ class ALPINE:
         self.loss_type = loss_type
         self.eps = eps
         self.random_state = random_state
-        # extension (not in the reference): shard the cell axis over the ranks of the default
-        # torch.distributed process group, one process per GPU.  Default: single device.
+        # extension (not in the reference): shard the cell axis over the ranks of the default torch.distributed process
+        # group, one process per GPU.  False: single device.  True: every rank passes the SAME full adata and keeps its
+        # contiguous block of cells; all ranks return the full factors.  "local": every rank passes ONLY its own cells
+        # (rank order = cell order; a 20k x 1M matrix never has to exist in one process) and gets its own columns of H.
+        if shard_cells not in (False, True, "local"):
+            raise ValueError("shard_cells must be False, True or 'local'")
         self.shard_cells = shard_cells
         # extension: storage / matrix-pipe mode of the two sweeps (the reference has float32 only).
         #   "x3" (default)  X float32 in HBM; every product is formed from the exact bf16 planes of both factors on the
@@ -123,7 +127,7 @@ class ALPINE:
 
         n_sample = adata.shape[0]
         self.fe = FeatureEncoders(covariate_keys)
-        Y = self.fe.fit_transform(adata.obs)                       # list of N x C_i float32 (main.py:108-109)
+        Y = self.fe.fit_transform(adata.obs, merge_categories=self._category_merger())   # list of N x C_i float32 (main.py:108-109)
         self.batch_size = batch_size if batch_size is not None else n_sample
         self._check_supported(n_sample)
 
@@ -150,6 +154,24 @@ class ALPINE:
         self.store_embeddings(adata)
         return self
 
+    def _dist_world(self):
+        import torch.distributed as dist
+        if bool(self.shard_cells) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist, dist.get_rank(), dist.get_world_size()
+        return None, 0, 1
+
+    def _category_merger(self):
+        """shard_cells='local': labels that occur only on other ranks must still get a one-hot column here."""
+        dist, _, world = self._dist_world()
+        if self.shard_cells != "local" or dist is None:
+            return None
+
+        def merge(cats: np.ndarray) -> np.ndarray:
+            parts = [None] * world
+            dist.all_gather_object(parts, cats.tolist())
+            return np.unique(np.array([c for p in parts for c in p], dtype=object if cats.dtype == object else None))
+        return merge
+
     def _check_supported(self, n_sample: int) -> None:
         if self.use_als and self.shard_cells:
             raise NotImplementedError("use_als=True is single-device (the group loop needs HH^T of all cells after every group)")
@@ -170,15 +192,28 @@ class ALPINE:
     def _run_native(self, X_cells_genes: np.ndarray, Y: List[np.ndarray], n_iter: int, scale: bool) -> dict:
         """Upload, initialise exactly like main.py:436-472, run the MU loop on the device(s), read back."""
         N_total, G = X_cells_genes.shape
+        uses_batches = self._uses_batches(N_total)          # decided on the cells this process was given
         dev_index = _parse_device(str(self.device))
-        import torch.distributed as dist
-        sharded = bool(self.shard_cells) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        dist, rank, world = self._dist_world()
+        sharded = dist is not None
+        local_input = sharded and self.shard_cells == "local"
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: alpine_amd needs an MI355X (there is no CPU fallback)")
         if dev_index < 0:
             dev_index = torch.cuda.current_device()
-        rank, world = (dist.get_rank(), dist.get_world_size()) if sharded else (0, 1)
-        c0, c1 = shard_bounds(N_total, world, rank)
+        if local_input:
+            # every rank holds only its own cells: the global cell order is rank order
+            sizes = [None] * world
+            dist.all_gather_object(sizes, (int(N_total), int(G)))
+            if any(g != G for _, g in sizes):
+                raise ValueError("shard_cells='local': all ranks must pass the same genes")
+            row0 = 0                                   # first local row of X / Y that belongs to this shard
+            c0 = sum(n for n, _ in sizes[:rank])
+            N_total = sum(n for n, _ in sizes)
+            c1 = c0 + sizes[rank][0]
+        else:
+            c0, c1 = shard_bounds(N_total, world, rank)
+            row0 = c0
         n_loc = c1 - c0
         cov_levels = [y.shape[1] for y in Y]
         W0, H0, B0 = draw_initial_factors(self.random_state, self.eps, G, N_total, self.n_all_components, cov_levels)
@@ -190,12 +225,12 @@ class ALPINE:
 
         x_dtype = self.x_dtype
         if x_dtype == "auto":
-            x_dtype = "x3" if self._uses_batches(N_total) else "split"
+            x_dtype = "x3" if uses_batches else "split"
         kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
                   loss_type=self.loss_type, device_id=dev_index, x_dtype=x_dtype,
-                  batch_capacity=(min(self.batch_size, N_total) if self._uses_batches(N_total) else 0),
+                  batch_capacity=(min(self.batch_size, N_total) if uses_batches else 0),
                   use_als=self.use_als)
         block, stream = None, None
         if sharded:
@@ -213,9 +248,9 @@ class ALPINE:
             e = _native.NativeShard(**{**kw, "x_dtype": dtype})
             try:
                 chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)    # multiple of 8 cells (bf16 paths pack 8 rows per granule)
-                for r0 in range(c0, c1, chunk):
-                    r1 = min(c1, r0 + chunk)
-                    e.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r1], dtype=np.float32), _native.X_CELLS_BY_GENES, r0 - c0)
+                for r0 in range(row0, row0 + n_loc, chunk):
+                    r1 = min(row0 + n_loc, r0 + chunk)
+                    e.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r1], dtype=np.float32), _native.X_CELLS_BY_GENES, r0 - row0)
                 e.finalize_X()
             except Exception:
                 e.close()
@@ -234,7 +269,7 @@ class ALPINE:
         self.x_dtype_used = x_dtype
         try:
             for i, y in enumerate(Y):
-                eng.upload_Y(i, np.ascontiguousarray(y[c0:c1].T))
+                eng.upload_Y(i, np.ascontiguousarray(y[row0:row0 + n_loc].T))
             eng.set_factors(W0, H0, B0, h_col0=c0)
             if kw.get("batch_capacity", 0) > 0:
                 self._run_epochs(eng, Y, N_total, n_iter)
@@ -264,14 +299,14 @@ class ALPINE:
             info_d = {f: getattr(info, f) for f, _ in info._fields_}
         finally:
             eng.close()
-        if sharded:
+        if sharded and not local_input:
             H = np.empty((self.total_components, N_total), dtype=np.float32)
             parts = [None] * world
             dist.all_gather_object(parts, (c0, c1, H_loc))
             for a, b, h in parts:
                 H[:, a:b] = h
         else:
-            H = H_loc
+            H = H_loc                                   # single device, or rank-local input: this rank's cells only
         colnames = ["total loss", "reconstruction loss"] + [f"prediction loss({k})" for k in self.covariate_keys]
         return dict(W=W, H=H, Bs=Bs, loss_history=pd.DataFrame(losses, columns=colnames), info=info_d)
 

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, out_dir):
+def _worker(rank, world, port, case_name, out_dir, local=False):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -31,8 +31,16 @@ def _worker(rank, world, port, case_name, out_dir):
     from _golden import load_case
     from alpine_amd import ALPINE, MiniAnnData
     c = load_case(case_name)
-    adata = MiniAnnData(c.X.copy(), c.obs.copy())
-    m = ALPINE(device="cuda:0", shard_cells=True, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
+    if local:
+        # rank-local input: an UNEVEN, unaligned split in rank order (rank 0 gets the first third of the cells)
+        n = c.X.shape[0]
+        cut = [0, n // 3 + 1, n]
+        adata = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
+        m = ALPINE(device="cuda:0", shard_cells="local", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
+        assert adata.obsm["ALPINE_embedding"].shape[0] == cut[rank + 1] - cut[rank]
+    else:
+        adata = MiniAnnData(c.X.copy(), c.obs.copy())
+        m = ALPINE(device="cuda:0", shard_cells=True, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=np.concatenate(m.matrices["Ws"], axis=1),
              H=np.concatenate(m.matrices["Hs"], axis=0), losses=m.loss_history.to_numpy(),
              **{f"B{i}": b for i, b in enumerate(m.matrices["Bs"])})
@@ -57,4 +65,26 @@ def test_two_ranks_one_gpu(case_name, tmp_path):
     assert rel_fro(r[0]["W"], c.WT) < 1e-4 and rel_fro(r[0]["H"], c.HT) < 1e-4
     for i, bt in enumerate(c.BT):
         assert rel_fro(r[0][f"B{i}"], bt) < 2e-4
+    assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
+
+
+@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "counts_2cov"])
+def test_two_ranks_local_input(case_name, tmp_path):
+    """shard_cells='local': each rank passes only its own cells (uneven split); W, B and the loss history equal the
+    single-process run, the ranks' H columns concatenate to its H, labels missing on one rank still get their column."""
+    import torch.multiprocessing as mp
+    from _golden import assert_loss_rows_close, load_case, rel_fro
+    from alpine_amd import ALPINE, MiniAnnData
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), case_name, str(tmp_path), True), nprocs=world, join=True)
+    c = load_case(case_name)
+    single = ALPINE(device="cuda:0", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
+    W1 = np.concatenate(single.matrices["Ws"], axis=1)
+    H1 = np.concatenate(single.matrices["Hs"], axis=0)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert np.array_equal(r[0]["W"], r[1]["W"]) and np.array_equal(r[0]["losses"], r[1]["losses"])
+    H = np.concatenate([r[0]["H"], r[1]["H"]], axis=1)
+    assert H.shape == H1.shape
+    assert rel_fro(r[0]["W"], W1) < 5e-6 and rel_fro(H, H1) < 5e-6
+    assert rel_fro(r[0]["W"], c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
     assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
