@@ -677,7 +677,14 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         if (getenv_is("ALPINE_HIP_ABLATE_FLUSH", '1')) gx.panel_fixed = 2;
         switch (c->KT) {
             case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
-            case 2: hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            case 2: {
+                const char* ab = std::getenv("ALPINE_HIP_X3_ABLATE");      // timing-only diagnostics (wrong results)
+                const int abl = ab ? std::atoi(ab) : 0;
+                if (abl == 1) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else if (abl == 2) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else if (abl == 3) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+            } break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
             default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
         }

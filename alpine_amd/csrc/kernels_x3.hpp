@@ -50,7 +50,7 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 (&b)[3])
 // One panel stage = X3_RING k-steps.  Per k-step: A fragments of all three panel planes (double-buffered over k-steps),
 // then per 128-column half: 4 x (split one tile's 8 x float32 into planes, 6*KT MFMAs), then the half's 8 loads are
 // re-issued for the same k-step of the next stage.
-template <int KT, int NH, bool LAST>
+template <int KT, int NH, bool LAST, int ABL = 0>
 __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X3_RING][NH][8], const unsigned short* __restrict__ lrow,
                                          const float* __restrict__ xnext0, const float* __restrict__ xnext1, int64_t ldS, int lds_plane)
 {
@@ -80,11 +80,17 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = x[p][hf][e][t];
                 u32x4 b[3];
-                x3_split8(v, b);
+                if constexpr (ABL == 2) {                      // timing-only ablation: no split (raw bits as operands)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b[q] = u32x4{__float_as_uint(v[0]) + __float_as_uint(v[1]), __float_as_uint(v[2]) + __float_as_uint(v[3]),
+                                                             __float_as_uint(v[4]) + __float_as_uint(v[5]), __float_as_uint(v[6]) + __float_as_uint(v[7])};
+                } else {
+                    x3_split8(v, b);
+                }
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
-                    for (int xp = 0; xp + pp <= 2; ++xp)
+                    for (int xp = 0; xp + pp <= (ABL == 3 ? 1 : 2); ++xp)   // ABL == 3: timing-only, 3 of the 6 products
 #pragma unroll
                         for (int m = 0; m < KT; ++m)
                             acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][pp][m]),
@@ -102,7 +108,7 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
     }
 }
 
-template <int KT, int NH>
+template <int KT, int NH, int ABL = 0>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
                            int64_t ldS, SweepGeom g)
@@ -214,8 +220,8 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
             store_p((t + 1) & 1);
             load_p(t + 2);
             __builtin_amdgcn_sched_barrier(0);
-            x3_stage<KT, NH, false>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
-            __syncthreads();
+            x3_stage<KT, NH, false, ABL>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
+            if constexpr (ABL != 1) __syncthreads();           // ABL == 1: timing-only ablation of the stage barrier
         }
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
