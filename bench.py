@@ -333,6 +333,7 @@ def main():
                 "cells_per_gpu": n_loc, "k_padded": info.k_padded, "split_xht": info.split_a, "split_wtx": info.split_b,
                 "grid_xht": info.grid_a, "grid_wtx": info.grid_b, "device_GiB": round(info.device_bytes / 2**30, 2),
                 "parallelism": f"cells/{world}",
+                "x_scale": args.x_scale,      # 1.0 = the spec'd Poisson counts; throughput is value-dependent on this chip
             },
             "roofline": roofline(main_m),
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
