@@ -349,8 +349,17 @@ class ALPINE:
         if dev_index < 0:
             dev_index = torch.cuda.current_device()
         self._advance_rng_like_reference_fit()
-        # main.py:687-689: U[0,1) from the global generator, NOT reseeded, NOT clamped
-        H0 = torch.rand((self.total_components, n_sample), dtype=torch.float32).numpy()
+        # main.py:687-689: U[0,1) from the global generator, NOT reseeded, NOT clamped.  Rank-local inputs: every rank
+        # draws the init of ALL cells (rank order = cell order) and keeps its columns, so the result equals the
+        # single-process transform of the concatenated cells; cells are independent, no collective is needed.
+        dist, rank, world = self._dist_world()
+        if dist is not None and self.shard_cells == "local":
+            sizes = [None] * world
+            dist.all_gather_object(sizes, int(n_sample))
+            c0 = sum(sizes[:rank])
+            H0 = np.ascontiguousarray(torch.rand((self.total_components, sum(sizes)), dtype=torch.float32).numpy()[:, c0:c0 + n_sample])
+        else:
+            H0 = torch.rand((self.total_components, n_sample), dtype=torch.float32).numpy()
         W = np.ascontiguousarray(np.concatenate(self.matrices["Ws"], axis=1), dtype=np.float32)
         def make_engine(dtype):
             e = _native.NativeShard(n_genes=G, n_cells=n_sample, n_components=self.total_components, cov_components=[],

@@ -38,6 +38,11 @@ def _worker(rank, world, port, case_name, out_dir, local=False):
         adata = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
         m = ALPINE(device="cuda:0", shard_cells="local", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
         assert adata.obsm["ALPINE_embedding"].shape[0] == cut[rank + 1] - cut[rank]
+        if c.transform_iters:                      # transform of the rank's own cells right after the fit
+            a_t = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
+            m.transform(a_t, n_iter=c.transform_iters)
+            np.save(os.path.join(out_dir, f"transform_rank{rank}.npy"),
+                    np.concatenate([np.asarray(a_t.obsm[k]).T for k in c.keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0))
     else:
         adata = MiniAnnData(c.X.copy(), c.obs.copy())
         m = ALPINE(device="cuda:0", shard_cells=True, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
@@ -88,3 +93,10 @@ def test_two_ranks_local_input(case_name, tmp_path):
     assert rel_fro(r[0]["W"], W1) < 5e-6 and rel_fro(H, H1) < 5e-6
     assert rel_fro(r[0]["W"], c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
     assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
+    if c.transform_iters:
+        # transform of ALL cells in one process right after a fit == the ranks' local transforms side by side
+        a_t = MiniAnnData(c.X.copy(), c.obs.copy())
+        single.transform(a_t, n_iter=c.transform_iters)
+        Ht1 = np.concatenate([np.asarray(a_t.obsm[k]).T for k in c.keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0)
+        Ht = np.concatenate([np.load(tmp_path / f"transform_rank{i}.npy") for i in range(world)], axis=1)
+        assert rel_fro(Ht, Ht1) < 2e-5
