@@ -23,7 +23,7 @@ EXPORTS = [
     "alpine_reduce_block_floats", "alpine_create", "alpine_destroy", "alpine_last_error", "alpine_get_info",
     "alpine_upload_X_host", "alpine_upload_X_device", "alpine_finalize_X", "alpine_upload_Y",
     "alpine_set_factors", "alpine_get_factors", "alpine_iter_begin", "alpine_iter_end", "alpine_reduce_block",
-    "alpine_batch_step", "alpine_epoch_loss", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
+    "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_get_kernel_time", "alpine_read_buffer",
 ]
 
@@ -90,6 +90,10 @@ def load() -> C.CDLL:
     lib.alpine_transform.argtypes = [p, i32]
     lib.alpine_batch_step.argtypes = [p, p, i64]
     lib.alpine_epoch_loss.argtypes = [p]
+    lib.alpine_batch_begin.argtypes = [p, p, i64]
+    lib.alpine_batch_end.argtypes = [p]
+    lib.alpine_epoch_loss_begin.argtypes = [p]
+    lib.alpine_epoch_loss_end.argtypes = [p]
     lib.alpine_get_losses.argtypes = [p, C.POINTER(C.c_double), i64, C.POINTER(i64)]
     lib.alpine_reset_losses.argtypes = [p]
     lib.alpine_scale.argtypes = [p]
@@ -229,6 +233,19 @@ class NativeShard:
 
     def epoch_loss(self):
         self._chk(self._lib.alpine_epoch_loss(self._h))
+
+    def batch_begin(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        self._chk(self._lib.alpine_batch_begin(self._h, idx.ctypes.data if idx.size else None, idx.size))
+
+    def batch_end(self):
+        self._chk(self._lib.alpine_batch_end(self._h))
+
+    def epoch_loss_begin(self):
+        self._chk(self._lib.alpine_epoch_loss_begin(self._h))
+
+    def epoch_loss_end(self):
+        self._chk(self._lib.alpine_epoch_loss_end(self._h))
 
     def transform(self, n_iter: int):
         self._chk(self._lib.alpine_transform(self._h, n_iter))

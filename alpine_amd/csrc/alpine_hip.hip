@@ -54,6 +54,9 @@ struct alpine_ctx {
     float *piecesA = nullptr, *piecesB = nullptr;     // stream-K partial results of the two sweeps
     SweepGeom geomA{}, geomB{};
     CellView full{};                                  // the whole shard
+    CellView batch_view{};                            // view of the batch opened by alpine_batch_begin
+    bool batch_open = false;
+    int64_t batch_n = 0;
     // mini-batch view buffers (alpine_config.batch_capacity > 0)
     int64_t batch_cap = 0;
     float *Xb_gn = nullptr, *Xb_ng = nullptr, *Hb = nullptr, *Yb = nullptr;
@@ -865,13 +868,25 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
 
 // One mini-batch update (main.py:512-663 for one batch): the n cells idx[0..n) (local indices, duplicates allowed:
 // "weighted" sampling draws with replacement) are gathered into a contiguous view, the same phase 1 / phase 2 kernels
-// run on the view, and the updated rows of H are scattered back.
-extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
+// run on the view, and the updated rows of H are scattered back.  Split at the exchange point like an iteration:
+//   alpine_batch_begin : gather + sums over the batch's LOCAL cells -> reduce block   (n == 0 is allowed: a shard
+//                        that holds none of the batch's cells contributes zeros and still updates its replica of W, B)
+//   [ multi-GPU: the caller all-reduces the reduce block ]
+//   alpine_batch_end   : W, B updates, W^TX sweep and H update on the view, scatter
+extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
 {
     int rc = ready(c);
     if (rc) return rc;
     if (c->transform_only || c->bf16) return fail(c, ALPINE_ERR_UNSUPPORTED, "mini-batches need the float32 two-copy layout");
-    if (!idx || n <= 0 || n > c->batch_cap) return fail(c, ALPINE_ERR_BAD_ARG, "batch of %lld cells outside the ctx's batch_capacity %lld", (long long)n, (long long)c->batch_cap);
+    if (c->batch_open) return fail(c, ALPINE_ERR_STATE, "alpine_batch_begin: the previous batch was not ended");
+    if (n < 0 || n > c->batch_cap || (n > 0 && !idx))
+        return fail(c, ALPINE_ERR_BAD_ARG, "batch of %lld cells outside the ctx's batch_capacity %lld", (long long)n, (long long)c->batch_cap);
+    c->batch_n = n;
+    if (n == 0) {
+        HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream));
+        c->batch_open = true;
+        return 0;
+    }
     std::vector<int> h((size_t)n);
     for (int64_t j = 0; j < n; ++j) {
         if (idx[j] < 0 || idx[j] >= c->N) return fail(c, ALPINE_ERR_BAD_ARG, "batch index %lld out of range", (long long)idx[j]);
@@ -879,7 +894,7 @@ extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));           // idx_dev may still be read by the previous batch's scatter
     HIPCHK(c, hipMemcpy(c->idx_dev, h.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    const int KP = c->KP, G = c->G;
+    const int KP = c->KP;
     const int64_t Bp = round_up(n, 128);
     const int nb = c->n_cu * 8;
     // gather the view: rows of the cells x genes copy, rows of H, columns of Y; then the genes x cells copy by transpose
@@ -892,8 +907,7 @@ extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
         hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->Xb_ng, c->Gp, c->Xb_gn, Bp, (int)Bp, (int)c->Gp);
     }
     HIPCHK(c, hipGetLastError());
-    (void)G;
-    CellView v;
+    CellView& v = c->batch_view;
     v.Xgn = c->Xb_gn; v.Xng = c->Xb_ng; v.H = c->Hb; v.Y = c->Yb;
     v.N = (int)n; v.Np = Bp;
     v.gA = make_geom(c->Gp, Bp, c->slots, 0, c->sweep_bf);
@@ -903,25 +917,71 @@ extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
     v.statBlocks = (int)((n + HS_CELLS - 1) / HS_CELLS);
     v.gramBlocksH = (int)((Bp + 4 * GR_ROWS_PER_WAVE - 1) / (4 * GR_ROWS_PER_WAVE));
     if ((rc = phase1(c, v))) return rc;
-    if ((rc = phase2(c, v, true, false))) return rc;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Hb, (int64_t)KP, c->idx_dev, (int)n, c->H, (int64_t)KP, KP);
+    c->batch_open = true;
+    return 0;
+}
+
+extern "C" int alpine_batch_end(alpine_ctx* c)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (!c->batch_open) return fail(c, ALPINE_ERR_STATE, "alpine_batch_end without alpine_batch_begin");
+    c->batch_open = false;
+    if (c->batch_n == 0) {
+        // none of the batch's cells live here: only the replicated updates (W from the reduced sums, every B_i)
+        if (c->use_als) return fail(c, ALPINE_ERR_UNSUPPORTED, "empty local batches are not supported with ALPINE_FLAG_USE_ALS");
+        const float* HHt = c->red + c->red_hht;
+        if ((rc = launch_w_update(c, HHt, true, 0, c->K, false))) return rc;
+        if (c->n_cov > 0) {
+            hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
+                               HHt, c->meta, c->KP, (float)c->eps);
+            HIPCHK(c, hipGetLastError());
+            c->bcur ^= 1;
+        }
+        c->pending_loss = false;
+        return 0;
+    }
+    if ((rc = phase2(c, c->batch_view, true, false))) return rc;
+    const int nb = c->n_cu * 8;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Hb, (int64_t)c->KP, c->idx_dev, (int)c->batch_n, c->H, (int64_t)c->KP, c->KP);
     HIPCHK(c, hipGetLastError());
     c->pending_loss = false;
     return 0;
 }
 
-// Loss row of the CURRENT factors over the whole shard (main.py:666 after the batches of an epoch): full-view phase 1,
-// <XH^T, W> partials, trace-form finalise.  W^TW must be that of the current W (it is, after any update step).
-extern "C" int alpine_epoch_loss(alpine_ctx* c)
+extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
+{
+    if (c && n <= 0) return fail(c, ALPINE_ERR_BAD_ARG, "batch of %lld cells outside the ctx's batch_capacity %lld", (long long)n, (long long)c->batch_cap);
+    const int rc = alpine_batch_begin(c, idx, n);
+    return rc ? rc : alpine_batch_end(c);
+}
+
+// Loss row of the CURRENT factors over all cells (main.py:666 after the batches of an epoch): full-view phase 1,
+// [multi-GPU: all-reduce], <XH^T, W> partials, trace-form finalise.  W^TW is refreshed from the current W.
+extern "C" int alpine_epoch_loss_begin(alpine_ctx* c)
 {
     int rc = ready(c);
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
+    if (c->batch_open) return fail(c, ALPINE_ERR_STATE, "alpine_epoch_loss_begin inside an open batch");
     if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
-    if ((rc = phase1(c, c->full))) return rc;
+    return phase1(c, c->full);
+}
+
+extern "C" int alpine_epoch_loss_end(alpine_ctx* c)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
     if ((rc = phase2(c, c->full, false, true))) return rc;
     c->pending_loss = false;
     return 0;
+}
+
+extern "C" int alpine_epoch_loss(alpine_ctx* c)
+{
+    const int rc = alpine_epoch_loss_begin(c);
+    return rc ? rc : alpine_epoch_loss_end(c);
 }
 
 extern "C" int alpine_transform(alpine_ctx* c, int n_iter)

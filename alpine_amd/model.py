@@ -128,8 +128,9 @@ class ALPINE:
         n_sample = adata.shape[0]
         self.fe = FeatureEncoders(covariate_keys)
         Y = self.fe.fit_transform(adata.obs, merge_categories=self._category_merger())   # list of N x C_i float32 (main.py:108-109)
-        self.batch_size = batch_size if batch_size is not None else n_sample
-        self._check_supported(n_sample)
+        n_global = self._global_cells(n_sample)                    # == n_sample unless shard_cells="local"
+        self.batch_size = batch_size if batch_size is not None else n_global
+        self._check_supported(n_global)
 
         if max_iter is None:
             # main.py:116-129: 200-iteration warm-up, Kneedle elbow on log10(recon loss)
@@ -160,6 +161,14 @@ class ALPINE:
             return dist, dist.get_rank(), dist.get_world_size()
         return None, 0, 1
 
+    def _global_cells(self, n_local: int) -> int:
+        dist, _, world = self._dist_world()
+        if dist is None or self.shard_cells != "local":
+            return n_local
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(n_local))
+        return int(sum(sizes))
+
     def _category_merger(self):
         """shard_cells='local': labels that occur only on other ranks must still get a one-hot column here."""
         dist, _, world = self._dist_world()
@@ -178,8 +187,6 @@ class ALPINE:
         if self.sampling_method not in ("random", "weighted"):
             raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
         if self._uses_batches(n_sample):
-            if self.shard_cells:
-                raise NotImplementedError("mini-batch / weighted sampling is single-device for now (no shard_cells)")
             if self.x_dtype not in ("f32", "x3", "auto"):
                 raise NotImplementedError("mini-batch / weighted sampling needs float32 storage: x_dtype='f32', 'x3' or 'auto'")
 
@@ -192,7 +199,6 @@ class ALPINE:
     def _run_native(self, X_cells_genes: np.ndarray, Y: List[np.ndarray], n_iter: int, scale: bool) -> dict:
         """Upload, initialise exactly like main.py:436-472, run the MU loop on the device(s), read back."""
         N_total, G = X_cells_genes.shape
-        uses_batches = self._uses_batches(N_total)          # decided on the cells this process was given
         dev_index = _parse_device(str(self.device))
         dist, rank, world = self._dist_world()
         sharded = dist is not None
@@ -215,6 +221,7 @@ class ALPINE:
             c0, c1 = shard_bounds(N_total, world, rank)
             row0 = c0
         n_loc = c1 - c0
+        uses_batches = self._uses_batches(N_total)          # N_total is the global cell count from here on
         cov_levels = [y.shape[1] for y in Y]
         W0, H0, B0 = draw_initial_factors(self.random_state, self.eps, G, N_total, self.n_all_components, cov_levels)
         # The reference's loop also draws torch.randperm(N) once per iteration from the global generator
@@ -230,7 +237,7 @@ class ALPINE:
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
                   loss_type=self.loss_type, device_id=dev_index, x_dtype=x_dtype,
-                  batch_capacity=(min(self.batch_size, N_total) if uses_batches else 0),
+                  batch_capacity=(min(self.batch_size, N_total) if uses_batches else 0),     # a whole batch may fall into one shard
                   use_als=self.use_als)
         block, stream = None, None
         if sharded:
@@ -272,7 +279,12 @@ class ALPINE:
                 eng.upload_Y(i, np.ascontiguousarray(y[row0:row0 + n_loc].T))
             eng.set_factors(W0, H0, B0, h_col0=c0)
             if kw.get("batch_capacity", 0) > 0:
-                self._run_epochs(eng, Y, N_total, n_iter)
+                if sharded:
+                    with torch.cuda.device(dev_index), torch.cuda.stream(stream):
+                        self._run_epochs(eng, Y, N_total, n_iter, comm=TorchDistComm(block), c0=c0, c1=c1,
+                                         gather_labels=dist if local_input else None)
+                else:
+                    self._run_epochs(eng, Y, N_total, n_iter)
             elif sharded:
                 with torch.cuda.device(dev_index), torch.cuda.stream(stream):
                     ShardedLoop(eng, TorchDistComm(block)).run(n_iter, with_loss=True)
@@ -405,24 +417,45 @@ class ALPINE:
         inv = np.asarray(inv).reshape(-1)
         return (codes.shape[0] / (len(cnt) * cnt.astype(np.float64)))[inv]
 
-    def _run_epochs(self, eng, Y: List[np.ndarray], n_total: int, n_iter: int) -> None:
+    def _run_epochs(self, eng, Y: List[np.ndarray], n_total: int, n_iter: int, comm=None, c0: int = 0, c1: Optional[int] = None,
+                    gather_labels=None) -> None:
         """The epoch/batch structure of main.py:500-521 with the reference's own index streams (drawn from the global
         torch generator right after the init draws): 'random' = torch.randperm(N) (sampling.py:14); 'weighted' =
         WeightedRandomSampler(weights, N, replacement=True) == torch.multinomial(weights as float64, N, True)
-        (sampling.py:18-33).  Each batch is one alpine_batch_step; one loss row over all cells per epoch."""
+        (sampling.py:18-33).  Each batch is one alpine_batch_step; one loss row over all cells per epoch.
+        Sharded (``comm``): every rank draws the SAME global index stream (same seed), takes the indices that fall into
+        its block [c0, c1) -- possibly none -- and the reduce block is all-reduced between alpine_batch_begin and
+        alpine_batch_end (and between the two halves of the epoch loss)."""
         self._rng_replay = None                                     # the stream is consumed for real here
         weights = None
         if self.sampling_method == "weighted":
-            weights = torch.as_tensor(self._balanced_joint_weights(Y), dtype=torch.double)
+            Y_all = Y
+            if gather_labels is not None:                           # rank-local inputs: the weights need every cell's labels
+                parts = [None] * gather_labels.get_world_size()
+                gather_labels.all_gather_object(parts, [np.asarray(y) for y in Y])
+                Y_all = [np.concatenate([p[i] for p in parts], axis=0) for i in range(len(Y))]
+            weights = torch.as_tensor(self._balanced_joint_weights(Y_all), dtype=torch.double)
         bs = self.batch_size
+        c1 = n_total if c1 is None else c1
         for _ in range(n_iter):
             if weights is not None:
                 epoch = torch.multinomial(weights, n_total, True).numpy()
             else:
                 epoch = torch.randperm(n_total).numpy()
             for b0 in range(0, n_total, bs):
-                eng.batch_step(epoch[b0:min(b0 + bs, n_total)])
-            eng.epoch_loss()
+                batch = epoch[b0:min(b0 + bs, n_total)]
+                if comm is None:
+                    eng.batch_step(batch)
+                else:
+                    eng.batch_begin(batch[(batch >= c0) & (batch < c1)] - c0)
+                    comm.all_reduce()
+                    eng.batch_end()
+            if comm is None:
+                eng.epoch_loss()
+            else:
+                eng.epoch_loss_begin()
+                comm.all_reduce()
+                eng.epoch_loss_end()
 
     # ------------------------------------------------- store_embeddings (main.py:303-320)
     def store_embeddings(self, adata) -> None:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALPINE_HIP_ABI_VERSION 2
+#define ALPINE_HIP_ABI_VERSION 3
 
 typedef struct alpine_ctx alpine_ctx;
 
@@ -154,9 +154,20 @@ int alpine_reduce_block(alpine_ctx* ctx, void** dev_ptr, int64_t* n_floats);
  * stream exactly as the reference does (torch.randperm, or the weighted sampler with replacement) and feeds it one batch
  * at a time.  alpine_batch_step gathers the n cells idx[0..n) of the local shard into a contiguous view, runs the W, B
  * and H updates on that view and scatters the updated columns of H back (replaces X[:, idx] / H[:, idx] = ...).
- * alpine_epoch_loss appends the loss row of the current factors over ALL cells (main.py:666).  float32 layout only. */
+ * alpine_epoch_loss appends the loss row of the current factors over ALL cells (main.py:666).  float32 storage only.
+ * Both are split at the point where shards exchange data, like an iteration:
+ *   alpine_batch_begin(idx, n)  gather + sums over the batch's LOCAL cells -> reduce block; n == 0 is allowed here (a
+ *                               shard that holds none of the batch's cells contributes zeros)
+ *   [ caller all-reduces the reduce block ]
+ *   alpine_batch_end()          W and B updates (replicated), W^TX sweep and H update on the view, scatter
+ *   alpine_epoch_loss_begin() / [all-reduce] / alpine_epoch_loss_end()
+ * alpine_batch_step = begin + end, alpine_epoch_loss = begin + end (single shard). */
 int alpine_batch_step(alpine_ctx* ctx, const int64_t* idx, int64_t n);
+int alpine_batch_begin(alpine_ctx* ctx, const int64_t* idx, int64_t n);
+int alpine_batch_end(alpine_ctx* ctx);
 int alpine_epoch_loss(alpine_ctx* ctx);
+int alpine_epoch_loss_begin(alpine_ctx* ctx);
+int alpine_epoch_loss_end(alpine_ctx* ctx);
 
 /* Replaces the loop of ALPINE._fit for one device (main.py:500-667): n_iters iterations; with_loss!=0
  * also produces one loss row per iteration ([total, recon, pred_1..pred_C], main.py:726-753). */

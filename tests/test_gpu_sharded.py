@@ -21,6 +21,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, case_name, out_dir, local=False):
+    # (fit_kwargs of the golden case -- batch_size / sampling_method -- are passed through: sharded mini-batches)
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -36,7 +37,7 @@ def _worker(rank, world, port, case_name, out_dir, local=False):
         n = c.X.shape[0]
         cut = [0, n // 3 + 1, n]
         adata = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
-        m = ALPINE(device="cuda:0", shard_cells="local", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
+        m = ALPINE(device="cuda:0", shard_cells="local", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
         assert adata.obsm["ALPINE_embedding"].shape[0] == cut[rank + 1] - cut[rank]
         if c.transform_iters:                      # transform of the rank's own cells right after the fit
             a_t = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
@@ -45,7 +46,7 @@ def _worker(rank, world, port, case_name, out_dir, local=False):
                     np.concatenate([np.asarray(a_t.obsm[k]).T for k in c.keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0))
     else:
         adata = MiniAnnData(c.X.copy(), c.obs.copy())
-        m = ALPINE(device="cuda:0", shard_cells=True, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T)
+        m = ALPINE(device="cuda:0", shard_cells=True, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=np.concatenate(m.matrices["Ws"], axis=1),
              H=np.concatenate(m.matrices["Hs"], axis=0), losses=m.loss_history.to_numpy(),
              **{f"B{i}": b for i, b in enumerate(m.matrices["Bs"])})
@@ -100,3 +101,22 @@ def test_two_ranks_local_input(case_name, tmp_path):
         Ht1 = np.concatenate([np.asarray(a_t.obsm[k]).T for k in c.keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0)
         Ht = np.concatenate([np.load(tmp_path / f"transform_rank{i}.npy") for i in range(world)], axis=1)
         assert rel_fro(Ht, Ht1) < 2e-5
+
+
+@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", False), ("mb_weighted", True), ("full_weighted", True)])
+def test_two_ranks_minibatch(case_name, local, tmp_path):
+    """Mini-batch / weighted sampling sharded over two ranks: both draw the same global index stream, each takes the
+    batch's cells that fall into its block (sometimes none), the reduce block is all-reduced between batch_begin and
+    batch_end.  Must reproduce the REFERENCE's stochastic run (same tolerances as the single-device mini-batch test)."""
+    import torch.multiprocessing as mp
+    from _golden import assert_loss_rows_close, load_case, rel_fro
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), case_name, str(tmp_path), local), nprocs=world, join=True)
+    c = load_case(case_name)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert np.array_equal(r[0]["W"], r[1]["W"]) and np.array_equal(r[0]["losses"], r[1]["losses"])
+    H = np.concatenate([r[0]["H"], r[1]["H"]], axis=1) if local else r[0]["H"]
+    assert rel_fro(r[0]["W"], c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
+    for i, bt in enumerate(c.BT):
+        assert rel_fro(r[0][f"B{i}"], bt) < 2e-4
+    assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])

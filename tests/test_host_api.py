@@ -176,8 +176,8 @@ def test_fit_rejects_non_anndata_and_unsupported_modes():
         ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, verbose=1)
     with pytest.raises(NotImplementedError):
         ALPINE(use_als=True, shard_cells=True, **GOOD).fit(a, covariate_keys=["c"], max_iter=1)
-    with pytest.raises(NotImplementedError):
-        ALPINE(shard_cells=True, **GOOD).fit(a, covariate_keys=["c"], max_iter=1, batch_size=5)
+    with pytest.raises(ValueError, match="shard_cells must be"):
+        ALPINE(shard_cells="yes", **GOOD)
     with pytest.raises(NotImplementedError):
         ALPINE(x_dtype="bf16", **GOOD).fit(a, covariate_keys=["c"], max_iter=1, sampling_method="weighted")
     with pytest.raises(ValueError, match="Unknown sampling method"):
