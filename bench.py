@@ -260,11 +260,20 @@ def main():
             ms_b, n_b = eng.kernel_time(_native.KERNEL_SWEEP_WTX)
             losses = eng.losses()
             eng.set_profiling(False)
+            dt_noloss = None
+            if world == 1 and with_loss:
+                # secondary number: updates only.  The trace-form loss is a by-product of the next
+                # iteration's phase 1, so this differs from the headline by one loss_finalize launch per iteration.
+                eng.synchronize()
+                t1 = time.perf_counter()
+                eng.run(args.steps, with_loss=False)
+                eng.synchronize()
+                dt_noloss = time.perf_counter() - t1
         finally:
             eng.close()
             del block
             torch.cuda.empty_cache()
-        return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen)
+        return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen, dt_noloss=dt_noloss)
 
     DTYPE_LABEL = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate",
                    "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)",
@@ -337,6 +346,7 @@ def main():
             },
             "roofline": roofline(main_m),
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
+            "updates_only_iterations_per_s": (args.steps / main_m["dt_noloss"]) if main_m.get("dt_noloss") else None,
             "setup_s": main_m["t_gen"],
             "other_modes": others or None,
         }

@@ -11,7 +11,7 @@ for off, ch in synth_counts_device_chunks(N, G, rank=50, seed=0, device=dev):
     X[off:off + ch.shape[0]] = ch.cpu().numpy()
 print("host X built in %.1f s" % (time.perf_counter() - t))
 obs = pd.DataFrame({"cond": synth_labels_host(N, ["a", "b"], 1)})
-for dtype in ("f32", "auto"):
+for dtype in ("x3", "f32", "auto"):
     for rep in range(2):
         a = MiniAnnData(X, obs.copy())
         t = time.perf_counter()
