@@ -23,7 +23,7 @@ EXPORTS = [
     "alpine_reduce_block_floats", "alpine_create", "alpine_destroy", "alpine_last_error", "alpine_get_info",
     "alpine_upload_X_host", "alpine_upload_X_device", "alpine_finalize_X", "alpine_upload_Y",
     "alpine_set_factors", "alpine_get_factors", "alpine_iter_begin", "alpine_iter_end", "alpine_reduce_block",
-    "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
+    "alpine_als_begin", "alpine_als_group_begin", "alpine_als_group_end", "alpine_reduce_block_hht", "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_get_kernel_time", "alpine_read_buffer",
 ]
 
@@ -91,6 +91,10 @@ def load() -> C.CDLL:
     lib.alpine_batch_step.argtypes = [p, p, i64]
     lib.alpine_epoch_loss.argtypes = [p]
     lib.alpine_batch_begin.argtypes = [p, p, i64]
+    lib.alpine_als_begin.argtypes = [p]
+    lib.alpine_als_group_begin.argtypes = [p, C.c_int]
+    lib.alpine_als_group_end.argtypes = [p, C.c_int]
+    lib.alpine_reduce_block_hht.argtypes = [p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.alpine_batch_end.argtypes = [p]
     lib.alpine_epoch_loss_begin.argtypes = [p]
     lib.alpine_epoch_loss_end.argtypes = [p]
@@ -233,6 +237,20 @@ class NativeShard:
 
     def epoch_loss(self):
         self._chk(self._lib.alpine_epoch_loss(self._h))
+
+    def als_begin(self):
+        self._chk(self._lib.alpine_als_begin(self._h))
+
+    def als_group_begin(self, grp: int):
+        self._chk(self._lib.alpine_als_group_begin(self._h, grp))
+
+    def als_group_end(self, grp: int):
+        self._chk(self._lib.alpine_als_group_end(self._h, grp))
+
+    def reduce_block_hht(self):
+        off, n = C.c_int64(), C.c_int64()
+        self._chk(self._lib.alpine_reduce_block_hht(self._h, C.byref(off), C.byref(n)))
+        return int(off.value), int(n.value)
 
     def batch_begin(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int64)

@@ -803,6 +803,28 @@ static int launch_sweep_wtx(alpine_ctx* c, const CellView& v)
     return prof_end(c, ALPINE_KERNEL_SWEEP_WTX);
 }
 
+// Block-coordinate branch, one component group (main.py:525-588).  als_group_hht: H H^T of the view with the groups
+// before `grp` already updated (a sum over cells: in a sharded run the caller all-reduces that K x K slot of the reduce
+// block before als_group_update); als_group_update: W_grp with the block-local orthogonality term, W^TW, W^TX sweep, H_grp.
+static int als_group_hht(alpine_ctx* c, const CellView& v, int grp)
+{
+    if (grp == 0) return 0;                      // the reduce block of phase 1 already holds H H^T of the old H
+    return launch_gram(c, v.H, v.Np, v.gramBlocksH, c->red + c->red_hht);
+}
+
+static int als_group_update(alpine_ctx* c, const CellView& v, int grp)
+{
+    int rc;
+    int k_lo = 0;
+    for (int g = 0; g < grp; ++g) k_lo += c->cov_k[g];
+    const int k_hi = grp < c->n_cov ? k_lo + c->cov_k[grp] : c->K;
+    const float* HHt = c->red + c->red_hht;
+    if ((rc = launch_w_update(c, HHt, true, k_lo, k_hi, true))) return rc;
+    if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
+    if ((rc = launch_sweep_wtx(c, v))) return rc;
+    return launch_h_update(c, v, k_lo, k_hi, grp);
+}
+
 // phase 2 on a view: [loss row of the factors that produced the reduce block], W update, B updates, W^TW, W^TX sweep,
 // H update of the view's cells.  finalize: append a loss row (the reduce block must then describe the FULL shard).
 static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
@@ -834,15 +856,9 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
         return launch_h_update(c, v, 0, K, -1);
     }
     // block-coordinate branch, main.py:525-588: groups in the order [cov_1 .. cov_C, unguided]
-    int k_lo = 0;
     for (int grp = 0; grp <= c->n_cov; ++grp) {
-        const int k_hi = grp < c->n_cov ? k_lo + c->cov_k[grp] : K;
-        if (grp > 0 && (rc = launch_gram(c, v.H, v.Np, v.gramBlocksH, c->red + c->red_hht))) return rc;   // H H^T with groups < grp updated
-        if ((rc = launch_w_update(c, HHt, true, k_lo, k_hi, true))) return rc;
-        if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
-        if ((rc = launch_sweep_wtx(c, v))) return rc;
-        if ((rc = launch_h_update(c, v, k_lo, k_hi, grp))) return rc;
-        k_lo = k_hi;
+        if ((rc = als_group_hht(c, v, grp))) return rc;
+        if ((rc = als_group_update(c, v, grp))) return rc;
     }
     return 0;
 }
@@ -863,6 +879,62 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
     rc = phase2(c, c->full, update != 0, c->pending_loss && c->loss_enabled);
     if (rc) return rc;
     c->pending_loss = update != 0;
+    return 0;
+}
+
+// use_als iteration split at ITS exchange points (the group loop needs H H^T of all cells after every group):
+//   alpine_iter_begin -> [all-reduce the reduce block] -> alpine_als_begin          (pending loss row, all B updates)
+//   for grp in 0..C:  alpine_als_group_begin(grp) -> [grp > 0: all-reduce the H H^T slot] -> alpine_als_group_end(grp)
+// alpine_iter_end(ctx, 1) is exactly this sequence without the exchanges (single shard).
+extern "C" int alpine_als_begin(alpine_ctx* c)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only || !c->use_als) return fail(c, ALPINE_ERR_STATE, "alpine_als_begin needs a ctx created with ALPINE_FLAG_USE_ALS");
+    const float* HHt = c->red + c->red_hht;
+    const bool finalize = c->pending_loss && c->loss_enabled;
+    if ((rc = launch_w_update(c, HHt, false, 0, c->K, false))) return rc;        // dot partials of <XH^T, W_old> only
+    if (finalize) {
+        if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, HHt,
+                           c->red + c->red_stats, c->meta, c->nstat, c->KP, c->lam_dev, c->loss_dev + c->loss_rows * (c->n_cov + 2));
+        HIPCHK(c, hipGetLastError());
+        c->loss_rows++;
+    }
+    if (c->n_cov > 0) {
+        hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
+                           HHt, c->meta, c->KP, (float)c->eps);
+        HIPCHK(c, hipGetLastError());
+        c->bcur ^= 1;
+    }
+    c->pending_loss = true;
+    return 0;
+}
+
+extern "C" int alpine_als_group_begin(alpine_ctx* c, int grp)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only || !c->use_als) return fail(c, ALPINE_ERR_STATE, "ctx was not created with ALPINE_FLAG_USE_ALS");
+    if (grp < 0 || grp > c->n_cov) return fail(c, ALPINE_ERR_BAD_ARG, "group %d outside [0, %d]", grp, c->n_cov);
+    return als_group_hht(c, c->full, grp);
+}
+
+extern "C" int alpine_als_group_end(alpine_ctx* c, int grp)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->transform_only || !c->use_als) return fail(c, ALPINE_ERR_STATE, "ctx was not created with ALPINE_FLAG_USE_ALS");
+    if (grp < 0 || grp > c->n_cov) return fail(c, ALPINE_ERR_BAD_ARG, "group %d outside [0, %d]", grp, c->n_cov);
+    return als_group_update(c, c->full, grp);
+}
+
+// where the K x K H H^T slot sits inside the reduce block (for the per-group exchange of the use_als branch)
+extern "C" int alpine_reduce_block_hht(alpine_ctx* c, int64_t* offset_floats, int64_t* n_floats)
+{
+    if (!c || !offset_floats || !n_floats) return fail(c, ALPINE_ERR_BAD_ARG, "NULL argument");
+    *offset_floats = c->red_hht;
+    *n_floats = (int64_t)c->KP * c->KP;
     return 0;
 }
 

@@ -182,11 +182,11 @@ class ALPINE:
         return merge
 
     def _check_supported(self, n_sample: int) -> None:
-        if self.use_als and self.shard_cells:
-            raise NotImplementedError("use_als=True is single-device (the group loop needs HH^T of all cells after every group)")
         if self.sampling_method not in ("random", "weighted"):
             raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
         if self._uses_batches(n_sample):
+            if self.use_als and self.shard_cells:
+                raise NotImplementedError("use_als=True with mini-batches is single-device (sharded: full batch only)")
             if self.x_dtype not in ("f32", "x3", "auto"):
                 raise NotImplementedError("mini-batch / weighted sampling needs float32 storage: x_dtype='f32', 'x3' or 'auto'")
 
@@ -287,7 +287,7 @@ class ALPINE:
                     self._run_epochs(eng, Y, N_total, n_iter)
             elif sharded:
                 with torch.cuda.device(dev_index), torch.cuda.stream(stream):
-                    ShardedLoop(eng, TorchDistComm(block)).run(n_iter, with_loss=True)
+                    ShardedLoop(eng, TorchDistComm(block), als_groups=(len(cov_levels) + 1 if self.use_als else 0)).run(n_iter, with_loss=True)
             elif self.verbose:
                 # main.py:490-494, :669-671: tqdm bar with the objective loss.  The loop runs asynchronously on the device,
                 # so the bar advances in chunks (one host sync per chunk instead of one per iteration).

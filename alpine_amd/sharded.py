@@ -41,16 +41,32 @@ class TorchDistComm:
     def all_reduce(self) -> None:
         self._dist.all_reduce(self.block, op=self._dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_slice(self, offset: int, n: int) -> None:
+        """Sum-all-reduce of block[offset : offset + n] only (the H H^T slot between the groups of the use_als branch)."""
+        self._dist.all_reduce(self.block[offset:offset + n], op=self._dist.ReduceOp.SUM, group=self.group)
+
 
 class ShardedLoop:
-    def __init__(self, engine, comm):
+    def __init__(self, engine, comm, als_groups: int = 0):
+        """``als_groups`` > 0: block-coordinate branch (use_als) with that many component groups (covariates + 1); the
+        group loop needs H H^T of all cells after every group, i.e. one small extra all-reduce per group."""
         self.engine = engine
         self.comm = comm
+        self.als_groups = als_groups
+        self._hht = engine.reduce_block_hht() if als_groups > 0 else None
 
     def step(self, update: bool = True) -> None:
         self.engine.iter_begin()
         self.comm.all_reduce()
-        self.engine.iter_end(update)
+        if not update or self.als_groups == 0:
+            self.engine.iter_end(update)
+            return
+        self.engine.als_begin()
+        for grp in range(self.als_groups):
+            self.engine.als_group_begin(grp)
+            if grp > 0:
+                self.comm.all_reduce_slice(*self._hht)
+            self.engine.als_group_end(grp)
 
     def run(self, n_iters: int, with_loss: bool = True) -> None:
         for _ in range(n_iters):

@@ -53,8 +53,8 @@ enum {
     ALPINE_FLAG_X_BF16 = 2,
     /* use_als=True of the reference (main.py:55, :523-588): block-coordinate updates, one component group
      * (covariate blocks first, unguided last) at a time: W_j (orthogonality within the block only), then H_j, with
-     * HH^T / W^TW refreshed between groups.  One XH^T sweep + (C+1) W^TX sweeps per iteration.  Single shard only
-     * (the group loop needs the up-to-date HH^T of ALL cells after every group). */
+     * HH^T / W^TW refreshed between groups.  One XH^T sweep + (C+1) W^TX sweeps per iteration.  With a sharded cell
+     * axis the group loop needs one more (K x K) exchange per group: alpine_als_begin / alpine_als_group_begin/end. */
     ALPINE_FLAG_USE_ALS = 4,
     /* exact-split storage: X is kept as one or two bf16 planes whose sum is EXACTLY the float32 input (integer counts
      * < 256 need one plane, 16 significant bits two), the MFMA operand copies of W / H as three bf16 planes that sum
@@ -149,6 +149,18 @@ int alpine_get_factors(alpine_ctx* ctx, float* W, float* H, int64_t ldH, float* 
 int alpine_iter_begin(alpine_ctx* ctx);
 int alpine_iter_end(alpine_ctx* ctx, int update);
 int alpine_reduce_block(alpine_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+
+/* use_als=True (ALPINE_FLAG_USE_ALS) with a sharded cell axis: the group loop (main.py:525-588) needs H H^T of ALL cells
+ * after every group, so the iteration has one more exchange per group:
+ *   alpine_iter_begin -> [all-reduce the reduce block] -> alpine_als_begin (pending loss row, all B updates)
+ *   for grp = 0 .. n_covariates:  alpine_als_group_begin(grp)  (grp > 0: local H H^T -> its slot of the reduce block)
+ *                                 [grp > 0: all-reduce that K_padded^2 slot, see alpine_reduce_block_hht]
+ *                                 alpine_als_group_end(grp)    (W_grp, W^TW, W^TX sweep, H_grp)
+ * A single shard just calls alpine_iter_end(ctx, 1), which is this sequence without the exchanges. */
+int alpine_als_begin(alpine_ctx* ctx);
+int alpine_als_group_begin(alpine_ctx* ctx, int grp);
+int alpine_als_group_end(alpine_ctx* ctx, int grp);
+int alpine_reduce_block_hht(alpine_ctx* ctx, int64_t* offset_floats, int64_t* n_floats);
 
 /* Mini-batch fitting (main.py:509-521, :512-663; alpine/utils/sampling.py:58-71): the caller draws the epoch's index
  * stream exactly as the reference does (torch.randperm, or the weighted sampler with replacement) and feeds it one batch

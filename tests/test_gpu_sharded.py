@@ -120,3 +120,21 @@ def test_two_ranks_minibatch(case_name, local, tmp_path):
     for i, bt in enumerate(c.BT):
         assert rel_fro(r[0][f"B{i}"], bt) < 2e-4
     assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
+
+
+@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True)])
+def test_two_ranks_use_als(case_name, local, tmp_path):
+    """Block-coordinate branch sharded over two ranks: one extra all-reduce of the K x K H H^T slot per component group."""
+    import torch.multiprocessing as mp
+    from _golden import assert_loss_rows_close, load_case, rel_fro
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), case_name, str(tmp_path), local), nprocs=world, join=True)
+    c = load_case(case_name)
+    assert c.params.get("use_als")
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert np.array_equal(r[0]["W"], r[1]["W"]) and np.array_equal(r[0]["losses"], r[1]["losses"])
+    H = np.concatenate([r[0]["H"], r[1]["H"]], axis=1) if local else r[0]["H"]
+    assert rel_fro(r[0]["W"], c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
+    for i, bt in enumerate(c.BT):
+        assert rel_fro(r[0][f"B{i}"], bt) < 2e-4
+    assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])

@@ -175,7 +175,7 @@ def test_fit_rejects_non_anndata_and_unsupported_modes():
     with pytest.raises(TypeError, match="verbose must be a boolean."):
         ALPINE(**GOOD).fit(a, covariate_keys=["c"], max_iter=1, verbose=1)
     with pytest.raises(NotImplementedError):
-        ALPINE(use_als=True, shard_cells=True, **GOOD).fit(a, covariate_keys=["c"], max_iter=1)
+        ALPINE(use_als=True, shard_cells=True, **GOOD).fit(a, covariate_keys=["c"], max_iter=1, batch_size=5)
     with pytest.raises(ValueError, match="shard_cells must be"):
         ALPINE(shard_cells="yes", **GOOD)
     with pytest.raises(NotImplementedError):

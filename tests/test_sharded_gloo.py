@@ -147,3 +147,24 @@ def test_loop_call_sequence():
     log.clear()
     ShardedLoop(E(), Cm()).run(1, with_loss=False)
     assert log == ["b", "r", "e1"]
+
+
+def test_loop_call_sequence_use_als():
+    """use_als: after the big all-reduce, one K x K all-reduce per component group except the first."""
+    from alpine_amd.sharded import ShardedLoop
+    log = []
+
+    class E:
+        def iter_begin(self): log.append("b")
+        def iter_end(self, update=True): log.append("e1" if update else "e0")
+        def als_begin(self): log.append("a")
+        def als_group_begin(self, g): log.append(f"g{g}")
+        def als_group_end(self, g): log.append(f"u{g}")
+        def reduce_block_hht(self): return (100, 16)
+
+    class Cm:
+        def all_reduce(self): log.append("r")
+        def all_reduce_slice(self, off, n): log.append(f"s{off}:{n}")
+
+    ShardedLoop(E(), Cm(), als_groups=3).run(1, with_loss=True)
+    assert log == ["b", "r", "a", "g0", "u0", "g1", "s100:16", "u1", "g2", "s100:16", "u2", "b", "r", "e0"]
