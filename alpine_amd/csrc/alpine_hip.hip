@@ -782,13 +782,14 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
 {
     const int KP = c->KP, K = c->K;
     const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
+    const size_t h_bytes_mfma = sizeof(float) * (KP * KP + ((std::max(1, c->nB) + 3) & ~3) + 4 * 32 * (KP + 4));   // + per-wave transpose scratch
     if (c->h_update_valu && !c->use_als) {   // reference implementation of the same update on the VALU (A/B and fallback)
         const int hblocks = (int)((v.N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
                                                c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
     } else {
         const int hblocks = (int)((v.N + 127) / 128);
-        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
                                                c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov));
     }
     HIPCHK(c, hipGetLastError());

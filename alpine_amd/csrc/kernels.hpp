@@ -756,6 +756,91 @@ __device__ __forceinline__ void sg_sum_pieces(const float* __restrict__ pieces, 
             out[m][q] = f32x4{(float)acc[m][q][0], (float)acc[m][q][1], (float)acc[m][q][2], (float)acc[m][q][3]};
 }
 
+// Row-major <-> C/D-layout exchange of one 32-row x KP tile through a wave-private LDS scratch tr[32][KP + 4].
+// Global memory is touched with whole rows only (a 32-row tile of a row-major [.][KP] array is one contiguous block of
+// 32*KP floats: lane L of instruction i reads / writes the 16 bytes at float offset 4*(64 i + L)); the C/D side is what
+// the MFMA formulation of the H / W updates needs (lane (c, h) owns k = 32m + 8q + 4h + e of row c).
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int KT>
+__device__ __forceinline__ void tile_lds_to_cd(const float* __restrict__ tr, int c, int h, f32x4 (&out)[KT][4])
+{
+    constexpr int LD = 32 * KT + 4;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[m][q] = *reinterpret_cast<const f32x4*>(&tr[c * LD + 32 * m + 8 * q + 4 * h]);
+}
+
+// tile rows (contiguous at src) -> C/D registers
+template <int KT>
+__device__ __forceinline__ void tile_load_cd(const float* __restrict__ src, float* __restrict__ tr, int lane, f32x4 (&out)[KT][4])
+{
+    constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4, NI = (32 * Q4) / 64;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = 64 * i + lane;
+        *reinterpret_cast<f32x4*>(&tr[(idx / Q4) * LD + 4 * (idx % Q4)]) = *reinterpret_cast<const f32x4*>(src + 4 * idx);
+    }
+    wave_lds_fence();
+    tile_lds_to_cd<KT>(tr, lane & 31, lane >> 5, out);
+    wave_lds_fence();
+}
+
+// C/D registers -> tile rows (contiguous at dst), rows >= rows_valid are not written
+template <int KT>
+__device__ __forceinline__ void tile_store_cd(float* __restrict__ dst, float* __restrict__ tr, int lane, const f32x4 (&in)[KT][4], int rows_valid)
+{
+    constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4, NI = (32 * Q4) / 64;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < KT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&tr[c * LD + 32 * m + 8 * q + 4 * h]) = in[m][q];
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = 64 * i + lane, r = idx / Q4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&tr[r * LD + 4 * (idx % Q4)]);
+        if (r < rows_valid) *reinterpret_cast<f32x4*>(dst + 4 * idx) = v;
+    }
+    wave_lds_fence();
+}
+
+// Sum of the pieces of tile ft for the 32 rows fl0 .. fl0+31 (ascending workgroup order: fixed, reproducible), read as
+// whole rows and handed over in C/D layout.  float accumulation: a handful of partial sums that are themselves float
+// sums over thousands of products.
+template <int KT>
+__device__ __forceinline__ void sg_sum_pieces_rows(const float* __restrict__ pieces, const SweepGeom& g, int ft, int fl0, int w_lo, int w_hi,
+                                                   float* __restrict__ tr, int lane, f32x4 (&out)[KT][4])
+{
+    constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4, NI = (32 * Q4) / 64;
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int w = w_lo; w <= w_hi; ++w) {
+        const float* base = pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl0 * KP;
+        f32x4 v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const f32x4*>(base + 4 * (64 * i + lane));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = 64 * i + lane;
+        *reinterpret_cast<f32x4*>(&tr[(idx / Q4) * LD + 4 * (idx % Q4)]) = acc[i];
+    }
+    wave_lds_fence();
+    tile_lds_to_cd<KT>(tr, lane & 31, lane >> 5, out);
+    wave_lds_fence();
+}
+
 // ----------------------------------------------------------------------------------------------
 // h_update on MFMA: one wave = 32 cells, lane (c, h) = cell n0+c, k-half h.
 //   den[k][cell] = sum_k' (2 W^TW)[k][k'] * H[cell][k']  as  D = A*B  with  A[k][k'] = M2 (symmetric, read transposed
@@ -766,7 +851,7 @@ __device__ __forceinline__ void sg_sum_pieces(const float* __restrict__ pieces, 
 // Guided terms (main.py:636-650) use the same registers: per covariate/class the lane forms its half of
 // (B_i H_i)[c'][cell] over the k it owns and adds the partner half (lane ^ 32).
 template <int KT>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
 void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
                           const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
                           CovMeta meta, int N, int64_t Np, int K, float eps, int nB, int k_lo, int k_hi, int only_cov)
@@ -782,6 +867,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
+    float* tr = smem + KP * KP + ((nB + 3) & ~3) + wave * (32 * (KP + 4));     // this wave's 32 x (KP + 4) transpose scratch
     for (int idx = tid; idx < KP * KP; idx += 256) M2l[idx] = 2.f * WtW[idx];
     for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];
     __syncthreads();
@@ -790,17 +876,14 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     if (n0 >= N) return;
     const int64_t n = n0 + c;
     const bool valid = n < N;
-    const int ft = (int)(n0 / g.bf), fl = (int)(n0 % g.bf) + c;
+    const int ft = (int)(n0 / g.bf), fl0 = (int)(n0 % g.bf);
     int w_lo, w_hi;
     sg_tile_pieces(g, ft, w_lo, w_hi);
 
+    // whole-row global accesses, C/D layout in registers (rows n0 .. n0+31 exist: H and the pieces are padded to 128 rows)
     f32x4 hreg[KT][4], xreg[KT][4];
-    sg_sum_pieces<KT>(pieces, g, ft, fl, w_lo, w_hi, h, valid, xreg);
-#pragma unroll
-    for (int m = 0; m < KT; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            hreg[m][q] = valid ? *reinterpret_cast<const f32x4*>(H + n * KP + 32 * m + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sg_sum_pieces_rows<KT>(pieces, g, ft, fl0, w_lo, w_hi, tr, lane, xreg);
+    tile_load_cd<KT>(H + n0 * KP, tr, lane, hreg);
 
     f32x16 acc[KT];
 #pragma unroll
@@ -819,12 +902,12 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                     acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], hreg[m][q][e], acc[mo], 0, 0, 0);
             }
 
-    // guided numerator / denominator for the k this lane owns in tiles 0..GT-1
-    f32x4 gnum[GT][4], gden[GT][4];
+    // numerator = 2 W^TX (+ guided), denominator = (2 W^TW) H (+ guided): accumulated IN PLACE in xreg / acc so that the
+    // kernel's live state stays at three tiles (H, numerator, denominator) -> 2 waves per SIMD
 #pragma unroll
-    for (int m = 0; m < GT; ++m)
+    for (int m = 0; m < KT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { gnum[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; gden[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int q = 0; q < 4; ++q) xreg[m][q] = 2.f * xreg[m][q];
     for (int i = 0; i < meta.n_cov; ++i) {
         if (only_cov >= 0 && i != only_cov) continue;
         const int off = meta.off[i], ki = meta.k[i], Ci = meta.lev[i], bo = meta.boff[i];
@@ -853,31 +936,26 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                     for (int e = 0; e < 4; ++e) {
                         const int k = 32 * m + 8 * q + 4 * h + e;
                         const float lb = (k >= off && k < off + ki) ? lam * brow[k] : 0.f;
-                        gnum[m][q][e] = fmaf(lb, z, gnum[m][q][e]);
-                        gden[m][q][e] = (meta.loss_type == 0) ? gden[m][q][e] + lb : fmaf(lb, bh, gden[m][q][e]);
+                        xreg[m][q][e] = fmaf(lb, z, xreg[m][q][e]);
+                        acc[m][4 * q + e] = (meta.loss_type == 0) ? acc[m][4 * q + e] + lb : fmaf(lb, bh, acc[m][4 * q + e]);
                     }
         }
     }
 
-    if (!valid) return;
 #pragma unroll
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k4 = 32 * m + 8 * q + 4 * h;
-            if (k4 >= K) continue;
-            f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float num = 2.f * xreg[m][q][e];
-                float den = acc[m][4 * q + e];
-                if (m < GT) { num = gnum[m < GT ? m : 0][q][e] + num; den = gden[m < GT ? m : 0][q][e] + den; }
-                const float v = hreg[m][q][e] * (num / fmaxf(den, eps));
+                const float v = hreg[m][q][e] * (xreg[m][q][e] / fmaxf(acc[m][4 * q + e], eps));
                 const int k = k4 + e;
-                o[e] = (k >= k_lo && k < k_hi) ? v : hreg[m][q][e];        // outside the range: unchanged (pads stay 0)
+                if (k >= k_lo && k < k_hi) hreg[m][q][e] = v;               // outside the range (and pads, which are 0): unchanged
             }
-            *reinterpret_cast<f32x4*>(H + n * KP + k4) = o;
         }
+    (void)K;
+    tile_store_cd<KT>(H + n0 * KP, tr, lane, hreg, (int)min((int64_t)32, (int64_t)N - n0));
 }
 
 // ----------------------------------------------------------------------------------------------
