@@ -477,6 +477,33 @@ def test_batch_step_argument_errors():
     eng.close()
 
 
+def test_split_entry_points_state_errors_and_empty_local_batch():
+    """begin/end pairs: order is enforced with status codes (no crash), and a shard that holds none of a batch's cells
+    (n == 0) still applies the replicated W / B updates from the reduce block."""
+    nat = _native()
+    c = load_case("kl_1cov")
+    eng = make_engine(c, batch_capacity=16)
+    with pytest.raises(nat.AlpineNativeError):
+        eng.batch_end()                           # nothing opened
+    eng.batch_begin(np.arange(8))
+    with pytest.raises(nat.AlpineNativeError):
+        eng.batch_begin(np.arange(8))             # previous batch still open
+    with pytest.raises(nat.AlpineNativeError):
+        eng.epoch_loss_begin()                    # inside an open batch
+    eng.batch_end()
+    with pytest.raises(nat.AlpineNativeError):
+        eng.als_begin()                           # ctx was not created with use_als
+    # empty local batch: reduce block is zeroed; W must then be multiplied by 0 / max(den, eps) -> exactly 0, B likewise
+    eng.batch_begin(np.empty(0, dtype=np.int64))
+    info = eng.info()
+    blk = eng.read_buffer(nat.BUF_REDUCE_BLOCK, 0, info.reduce_block_floats)
+    assert not blk.any()
+    eng.batch_end()
+    W, H, Bs = eng.get_factors()
+    assert not W.any() and np.isfinite(H).all()
+    eng.close()
+
+
 # ------------------------------------------------------------------ block-coordinate branch, use_als=True (next #3)
 @pytest.mark.parametrize("name", ALS_CASES)
 def test_als_drop_in_vs_reference(name):
