@@ -236,7 +236,25 @@ def main():
             eng.set_factors(W0, H0, B0, h_col0=c0)
             t_gen = time.perf_counter() - t_gen
             info = eng.info()
-            loop = ShardedLoop(eng, TorchDistComm(block)) if world > 1 else None
+            comm = None
+            if world > 1:
+                class TimedComm(TorchDistComm):
+                    """all-reduce bracketed by events on the engine's stream: the time an iteration spends between the
+                    end of its phase-1 kernels and the arrival of the reduced block (transfer + waiting for the slowest rank)."""
+                    def __init__(self, blk):
+                        super().__init__(blk)
+                        self.pairs, self.on = [], False
+
+                    def all_reduce(self):
+                        if not self.on:
+                            return super().all_reduce()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        super().all_reduce()
+                        e1.record()
+                        self.pairs.append((e0, e1))
+                comm = TimedComm(block)
+            loop = ShardedLoop(eng, comm) if world > 1 else None
 
             def run(n):
                 if loop is not None:
@@ -255,6 +273,8 @@ def main():
             fence()
             eng.reset_losses()
             eng.set_profiling(True)
+            if comm is not None:
+                comm.on = True
             t0 = time.perf_counter()
             run(args.steps)
             eng.synchronize()
@@ -265,6 +285,10 @@ def main():
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
+            ar_ms = None
+            if comm is not None:
+                comm.on = False
+                ar_ms = float(np.mean([a.elapsed_time(b) for a, b in comm.pairs])) if comm.pairs else None
             ms_a, n_a = eng.kernel_time(_native.KERNEL_SWEEP_XHT)
             ms_b, n_b = eng.kernel_time(_native.KERNEL_SWEEP_WTX)
             losses = eng.losses()
@@ -282,7 +306,7 @@ def main():
             eng.close()
             del block
             torch.cuda.empty_cache()
-        return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen, dt_noloss=dt_noloss)
+        return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen, dt_noloss=dt_noloss, ar_ms=ar_ms)
 
     DTYPE_LABEL = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate",
                    "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)",
@@ -355,6 +379,9 @@ def main():
             },
             "roofline": roofline(main_m),
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
+            "allreduce": ({"avg_ms_on_rank0": main_m["ar_ms"], "bytes": int(info.reduce_block_floats) * 4,
+                           "note": "events on the engine stream around dist.all_reduce: transfer + wait for the slowest rank"}
+                          if main_m.get("ar_ms") is not None else None),
             "updates_only_iterations_per_s": (args.steps / main_m["dt_noloss"]) if main_m.get("dt_noloss") else None,
             "setup_s": main_m["t_gen"],
             "other_modes": others or None,
