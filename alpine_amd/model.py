@@ -128,6 +128,10 @@ class ALPINE:
         n_sample = adata.shape[0]
         self.fe = FeatureEncoders(covariate_keys)
         Y = self.fe.fit_transform(adata.obs, merge_categories=self._category_merger())   # list of N x C_i float32 (main.py:108-109)
+        if len(Y) == 0:
+            # the reference cannot fit without covariates: _fit's prologue indexes Ys[0] (sampling.py:40, called from
+            # main.py:496) and raises this very error before the first iteration; reproduced, not "fixed"
+            raise IndexError("list index out of range")
         n_global = self._global_cells(n_sample)                    # == n_sample unless shard_cells="local"
         self.batch_size = batch_size if batch_size is not None else n_global
         self._check_supported(n_global)
