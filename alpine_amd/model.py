@@ -132,6 +132,9 @@ class ALPINE:
             # the reference cannot fit without covariates: _fit's prologue indexes Ys[0] (sampling.py:40, called from
             # main.py:496) and raises this very error before the first iteration; reproduced, not "fixed"
             raise IndexError("list index out of range")
+        if len(self.lam) < len(Y):
+            # len(lam) is never validated by the reference (main.py:322-381); its first iteration then fails on self.lam[i]
+            raise IndexError("list index out of range")
         n_global = self._global_cells(n_sample)                    # == n_sample unless shard_cells="local"
         self.batch_size = batch_size if batch_size is not None else n_global
         self._check_supported(n_global)

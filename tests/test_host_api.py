@@ -185,6 +185,9 @@ def test_fit_rejects_non_anndata_and_unsupported_modes():
     # zero covariates: the reference raises IndexError from its _fit prologue (sampling.py:40); same here, no GPU needed
     with pytest.raises(IndexError, match="list index out of range"):
         ALPINE(n_components=3, n_covariate_components=[], lam=[]).fit(a, covariate_keys=[], max_iter=1)
+    # len(lam) is not validated by the reference's constructor; a short list fails at the first self.lam[i] of the loop
+    with pytest.raises(IndexError, match="list index out of range"):
+        ALPINE(n_components=3, n_covariate_components=[2], lam=[]).fit(a, covariate_keys=["c"], max_iter=1)
 
 
 def test_synthetic_generator_is_count_like():
