@@ -87,14 +87,28 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
                 } else {
                     x3_split8(v, b);
                 }
+                // products with the hi plane of X: always
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
-                    for (int xp = 0; xp + pp <= (ABL == 3 ? 1 : 2); ++xp)   // ABL == 3: timing-only, 3 of the 6 products
+                    for (int m = 0; m < KT; ++m)
+                        acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][pp][m]),
+                                                                                     __builtin_bit_cast(bf16x8, b[0]), acc[m][4 * hf + t], 0, 0, 0);
+                // products with the mid / lo planes: nothing to add when the whole 16 x 32 tile of X is exactly one bf16
+                // plane (small integer counts, zeros) -- a wave-uniform test, no loads inside the branch
+                const unsigned rest = (b[1][0] | b[1][1] | b[1][2] | b[1][3]) & 0x7fff7fffu;
+                if (ABL != 3 && __builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
                         for (int m = 0; m < KT; ++m)
                             acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][pp][m]),
-                                                                                         __builtin_bit_cast(bf16x8, b[xp]), acc[m][4 * hf + t], 0, 0, 0);
+                                                                                         __builtin_bit_cast(bf16x8, b[1]), acc[m][4 * hf + t], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < KT; ++m)
+                        acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][0][m]),
+                                                                                     __builtin_bit_cast(bf16x8, b[2]), acc[m][4 * hf + t], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) {
