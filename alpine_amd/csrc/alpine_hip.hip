@@ -731,8 +731,12 @@ static int phase1(alpine_ctx* c, const CellView& v)
     int rc;
     const int KP = c->KP;
     if (c->n_cov > 0) {
-        hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), 0, c->stream, v.H, v.Y, c->B[c->bcur], c->meta,
-                           c->statPart, v.N, v.Np, KP, (float)c->eps, c->nstat);
+        int max_k = 1, max_c = 1;
+        for (int i = 0; i < c->n_cov; ++i) { max_k = std::max(max_k, c->cov_k[i]); max_c = std::max(max_c, c->cov_lev[i]); }
+        const int max_ct = std::min(HS_CT, max_c);
+        const size_t hs_bytes = sizeof(double) * HS_CELLS + sizeof(float) * ((size_t)(max_k + max_ct) * HS_CELLS + (size_t)max_ct * max_k);
+        hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hs_bytes, c->stream, v.H, v.Y, c->B[c->bcur], c->meta,
+                           c->statPart, v.N, v.Np, KP, (float)c->eps, c->nstat, max_k, max_ct);
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,

@@ -429,12 +429,15 @@ constexpr int HS_CT = 16;
 
 __global__ __launch_bounds__(HS_CELLS)
 void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, const float* __restrict__ B,
-                   CovMeta meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat)
+                   CovMeta meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat, int max_k, int max_ct)
 {
-    __shared__ float hbuf[MAX_COV_K][HS_CELLS];
-    __shared__ float zbuf[HS_CT][HS_CELLS];
-    __shared__ float Bl[HS_CT][MAX_COV_K];
-    __shared__ double lred[HS_CELLS];
+    // dynamic LDS sized for THIS model (max_k = largest k_i, max_ct = min(HS_CT, largest C_i)): a few KB instead of the
+    // 45 KB of worst-case static arrays, so that all blocks of a shard are resident at once and hide each other's latency
+    extern __shared__ __attribute__((aligned(16))) unsigned char hs_smem[];
+    double* lred = reinterpret_cast<double*>(hs_smem);                                   // [HS_CELLS]
+    float (*hbuf)[HS_CELLS] = reinterpret_cast<float (*)[HS_CELLS]>(lred + HS_CELLS);    // [max_k][HS_CELLS]
+    float (*zbuf)[HS_CELLS] = hbuf + max_k;                                              // [max_ct][HS_CELLS]
+    float* Blf = reinterpret_cast<float*>(zbuf + max_ct);                                // [max_ct][max_k]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t n = (int64_t)blockIdx.x * HS_CELLS + t;
     const bool valid = n < N;
@@ -451,11 +454,11 @@ void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, con
             const int ct = min(HS_CT, Ci - c0);
             __syncthreads();
             for (int idx = t; idx < ct * ki; idx += HS_CELLS)
-                Bl[idx / ki][idx % ki] = B[meta.boff[i] + (c0 + idx / ki) * ki + idx % ki];
+                Blf[(idx / ki) * max_k + idx % ki] = B[meta.boff[i] + (c0 + idx / ki) * ki + idx % ki];
             __syncthreads();
             for (int c = 0; c < ct; ++c) {
                 float bh = 0.f;
-                for (int k = 0; k < ki; ++k) bh = fmaf(Bl[c][k], hbuf[k][t], bh);
+                for (int k = 0; k < ki; ++k) bh = fmaf(Blf[c * max_k + k], hbuf[k][t], bh);
                 const float y = valid ? Y[(int64_t)(meta.yoff[i] + c0 + c) * Np + n] : 0.f;
                 float z;
                 if (meta.loss_type == 0) {
