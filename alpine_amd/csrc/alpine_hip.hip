@@ -90,6 +90,7 @@ struct alpine_ctx {
     std::string err;
     // timing-only ablation (env ALPINE_HIP_ABLATE_STRIDE0=1): the sweeps re-read row 0 of X (served from cache) -> wrong
     // results, prices the HBM stream against the MFMA pipeline.  Never set in tests or bench.
+    bool unfused_mid = false;         // env ALPINE_HIP_UNFUSED_MID=1: separate loss_finalize / b_update / gram launches (A/B)
     bool ablate_stride0 = false;
     bool ablate_panel = false;        // env ALPINE_HIP_ABLATE_PANEL=1: bf16 sweeps re-read panel stage 0 (timing only, wrong results)
     bool transform_only = false;
@@ -239,6 +240,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         return fail(c, ALPINE_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("ALPINE_HIP_ABLATE_STRIDE0")) c->ablate_stride0 = (e[0] == '1');
+    c->unfused_mid = getenv_is("ALPINE_HIP_UNFUSED_MID", '1');
     if (const char* e = std::getenv("ALPINE_HIP_ABLATE_PANEL")) c->ablate_panel = (e[0] == '1');
     if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
     if (const char* e = std::getenv("ALPINE_HIP_H_UPDATE")) c->h_update_valu = (std::strcmp(e, "valu") == 0);
@@ -739,14 +741,35 @@ static int phase1(alpine_ctx* c, const CellView& v)
                            c->statPart, v.N, v.Np, KP, (float)c->eps, c->nstat, max_k, max_ct);
         HIPCHK(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,
-                       v.statBlocks, c->nstat, c->xnorm2);
+    if (c->unfused_mid) {            // A/B: every reduction in its own launch
+        hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,
+                           v.statBlocks, c->nstat, c->xnorm2);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = launch_gram(c, v.H, v.Np, v.gramBlocksH, c->red + c->red_hht))) return rc;
+        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
+        if ((rc = launch_sweep(c, v.gA, v.Xng, v.H, c->piecesA, 0))) return rc;
+        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
+        return launch_reduce_pieces(c, c->piecesA, c->red, (int)c->Gp, v.gA);
+    }
+    // partial blocks of H H^T, then the sweep, then ONE launch for the three reductions that close phase 1
+    const int rpw = gram_rows_per_wave(v.Np, c->n_cu);
+    const int gblocks = (int)((v.Np + 4 * rpw - 1) / (4 * rpw));
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(gram_kernel<KT_>, dim3(gblocks), dim3(256), 0, c->stream, v.H, c->gramPart, (int)v.Np, rpw));
     HIPCHK(c, hipGetLastError());
-    if ((rc = launch_gram(c, v.H, v.Np, v.gramBlocksH, c->red + c->red_hht))) return rc;
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
     if ((rc = launch_sweep(c, v.gA, v.Xng, v.H, c->piecesA, 0))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-    return launch_reduce_pieces(c, c->piecesA, c->red, (int)c->Gp, v.gA);
+    Phase1Reduce a{};
+    const int64_t n4 = (int64_t)c->Gp * KP / 4;
+    a.nb_pieces = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu * 8, (n4 + 255) / 256));
+    a.nb_many = (KP * KP + 63) / 64;
+    a.nb_stats = c->nstat + 1;
+    a.pieces = c->piecesA; a.xht = c->red; a.rows = (int)c->Gp;
+    a.gram_part = c->gramPart; a.hht = c->red + c->red_hht; a.n_hht = KP * KP; a.n_slab = gblocks;
+    a.stat_part = c->statPart; a.kind = c->kind; a.stats = c->red + c->red_stats; a.stat_blocks = v.statBlocks; a.nstat = c->nstat; a.xnorm2 = c->xnorm2;
+    hipLaunchKernelGGL(phase1_reduce_kernel, dim3(a.nb_pieces + a.nb_many + a.nb_stats), dim3(256), 0, c->stream, a, KP, v.gA);
+    HIPCHK(c, hipGetLastError());
+    return 0;
 }
 
 static int grow_losses(alpine_ctx* c)
@@ -839,10 +862,31 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
     const float* HHt = c->red + c->red_hht;
     // MU: this launch also updates W; block-coordinate: dot partials only (the group loop below updates W)
     if ((rc = launch_w_update(c, HHt, update && !c->use_als, 0, K, false))) return rc;
+    if (finalize && c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
+    double* loss_row = c->loss_dev + c->loss_rows * (c->n_cov + 2);
+    if (update && !c->use_als && !c->unfused_mid) {
+        // MU branch: gram(W_new) partials, the pending loss row and the B updates share one launch (phase2_mid_kernel)
+        const int rpw = gram_rows_per_wave(c->Gp, c->n_cu);
+        Phase2Mid a{};
+        a.gram_blocks = (int)((c->Gp + 4 * rpw - 1) / (4 * rpw));
+        a.do_loss = finalize ? 1 : 0; a.do_b = c->n_cov > 0 ? 1 : 0;
+        a.dotpart = c->dotpart; a.ndot = c->ndot; a.WtW = c->WtW; a.HHt = HHt; a.stats = c->red + c->red_stats; a.nstat = c->nstat;
+        a.lam64 = c->lam_dev; a.row = loss_row;
+        a.Bold = c->B[c->bcur]; a.Bnew = c->B[c->bcur ^ 1]; a.eps = (float)c->eps;
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(phase2_mid_kernel<KT_>, dim3(a.gram_blocks + 2), dim3(256), 0, c->stream, c->W, c->gramPart,
+                                               (int)c->Gp, rpw, a, c->meta));
+        HIPCHK(c, hipGetLastError());
+        if (finalize) c->loss_rows++;
+        if (c->n_cov > 0) c->bcur ^= 1;
+        const int n = KP * KP;
+        hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, c->WtW, n, a.gram_blocks);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = launch_sweep_wtx(c, v))) return rc;
+        return launch_h_update(c, v, 0, K, -1);
+    }
     if (finalize) {
-        if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, HHt,
-                           c->red + c->red_stats, c->meta, c->nstat, KP, c->lam_dev, c->loss_dev + c->loss_rows * (c->n_cov + 2));
+                           c->red + c->red_stats, c->meta, c->nstat, KP, c->lam_dev, loss_row);
         HIPCHK(c, hipGetLastError());
         c->loss_rows++;
     }

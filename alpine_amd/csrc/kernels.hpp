@@ -301,12 +301,12 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
 }
 
 // out[f][k] = sum over the pieces of f's tile (ascending workgroup, float64 accumulation), f < rows
-__global__ __launch_bounds__(256)
-void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ out, int rows, int KP, SweepGeom g)
+__device__ __forceinline__ void reduce_pieces_block(const float* __restrict__ pieces, float* __restrict__ out, int rows, int KP, const SweepGeom& g,
+                                                    int block, int nblocks)
 {
     const int kq = KP / 4;
     const int64_t n4 = (int64_t)rows * kq;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < n4; i += (int64_t)nblocks * 256) {
         const int f = (int)(i / kq), k4 = (int)(i % kq);
         const int ft = f / g.bf, fl = f % g.bf;
         int w_lo, w_hi;
@@ -321,6 +321,12 @@ void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256)
+void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ out, int rows, int KP, SweepGeom g)
+{
+    reduce_pieces_block(pieces, out, rows, KP, g, blockIdx.x, gridDim.x);
+}
+
 // ----------------------------------------------------------------------------------------------
 // gram: part[b][k][k'] = sum_{r in rows of block b} A[r][k] * A[r][k']     (A: R x KP, row-major)
 // Used for HH^T (A = H) and W^TW (A = W).  Each wave owns a contiguous row range; A and B MFMA
@@ -328,13 +334,12 @@ void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ 
 constexpr int GR_ROWS_PER_WAVE = 256;      // upper bound; small matrices use fewer rows per wave to fill the chip
 
 template <int KT>
-__global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
-void gram_kernel(const float* __restrict__ A, float* __restrict__ part, int R, int rows_per_wave)
+__device__ __forceinline__ void gram_block(const float* __restrict__ A, float* __restrict__ part, int R, int rows_per_wave, int block)
 {
     constexpr int KP = 32 * KT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int gw = blockIdx.x * 4 + wave;
+    const int gw = block * 4 + wave;
     const int r0 = gw * rows_per_wave;
     const int r1 = min(R, r0 + rows_per_wave);         // R and rows_per_wave are multiples of 16
 
@@ -377,8 +382,15 @@ void gram_kernel(const float* __restrict__ A, float* __restrict__ part, int R, i
         }
         __syncthreads();
     }
-    float* out = part + (int64_t)blockIdx.x * KP * KP;
+    float* out = part + (int64_t)block * KP * KP;
     for (int idx = threadIdx.x; idx < KP * KP; idx += 256) out[idx] = gl[idx];
+}
+
+template <int KT>
+__global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
+void gram_kernel(const float* __restrict__ A, float* __restrict__ part, int R, int rows_per_wave)
+{
+    gram_block<KT>(A, part, R, rows_per_wave, blockIdx.x);
 }
 
 // out[j] = sum_s in[s][j], small n, many slabs: block = 64 outputs x 16 slab groups; groups are combined in group
@@ -503,12 +515,11 @@ void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, con
 // stats[j] = sum over blocks of part[blk][j] in float64; kind[j]: 0 plain, 1 = hi word of a (hi,lo) pair
 // whose lo word is j+1 (summed together, re-split), 2 = lo word (written by its hi's block).
 // Block nstat writes (hi,lo) of ||X_local||^2 at stats[nstat], stats[nstat+1].
-__global__ __launch_bounds__(256)
-void reduce_stats_kernel(const float* __restrict__ part, const int* __restrict__ kind, float* __restrict__ stats,
-                         int nblk, int nstat, double xnorm2)
+__device__ __forceinline__ void reduce_stats_block(const float* __restrict__ part, const int* __restrict__ kind, float* __restrict__ stats,
+                                                   int nblk, int nstat, double xnorm2, int j)
 {
     __shared__ double red[256];
-    const int j = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     if (j == nstat) {
         if (t == 0) {
             const float hi = (float)xnorm2;
@@ -535,6 +546,45 @@ void reduce_stats_kernel(const float* __restrict__ part, const int* __restrict__
         stats[j] = hi;
         if (kd == 1) stats[j + 1] = (float)(red[0] - (double)hi);
     }
+}
+
+__global__ __launch_bounds__(256)
+void reduce_stats_kernel(const float* __restrict__ part, const int* __restrict__ kind, float* __restrict__ stats,
+                         int nblk, int nstat, double xnorm2)
+{
+    reduce_stats_block(part, kind, stats, nblk, nstat, xnorm2, blockIdx.x);
+}
+
+// out[j] = sum_s in[s][j] with 256 threads: 64 outputs x 4 slab groups, groups combined in group order (float64)
+__device__ __forceinline__ void reduce_many_block256(const float* __restrict__ in, float* __restrict__ out, int n, int nslab, int block)
+{
+    __shared__ double red4[4][64];
+    const int j = block * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    double a = 0.0;
+    if (j < n) for (int sl = sg; sl < nslab; sl += 4) a += (double)in[(int64_t)sl * n + j];
+    red4[sg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (sg == 0 && j < n) out[j] = (float)(red4[0][threadIdx.x] + red4[1][threadIdx.x] + red4[2][threadIdx.x] + red4[3][threadIdx.x]);
+}
+
+// The three reductions that close phase 1 in ONE launch (they are independent of each other): the pieces of the XH^T
+// sweep, the partial blocks of H H^T and the per-block covariate statistics.  Blocks [0, nb_pieces) | [.., + nb_many) | rest.
+struct Phase1Reduce {
+    int nb_pieces, nb_many, nb_stats;
+    const float* pieces; float* xht; int rows;
+    const float* gram_part; float* hht; int n_hht, n_slab;
+    const float* stat_part; const int* kind; float* stats; int stat_blocks, nstat; double xnorm2;
+};
+
+__global__ __launch_bounds__(256)
+void phase1_reduce_kernel(Phase1Reduce a, int KP, SweepGeom g)
+{
+    int b = blockIdx.x;
+    if (b < a.nb_pieces) { reduce_pieces_block(a.pieces, a.xht, a.rows, KP, g, b, a.nb_pieces); return; }
+    b -= a.nb_pieces;
+    if (b < a.nb_many) { reduce_many_block256(a.gram_part, a.hht, a.n_hht, a.n_slab, b); return; }
+    b -= a.nb_many;
+    reduce_stats_block(a.stat_part, a.kind, a.stats, a.stat_blocks, a.nstat, a.xnorm2, b);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1121,8 +1171,7 @@ void h_iterate_mfma_kernel(float* __restrict__ H, const float* __restrict__ piec
 
 // ----------------------------------------------------------------------------------------------
 // b_update (one block): B_i <- B_i * num / max(den, eps), main.py:615-628, from the reduced statistics.
-__global__ __launch_bounds__(256)
-void b_update_kernel(const float* __restrict__ Bold, float* __restrict__ Bnew, const float* __restrict__ stats,
+__device__ __forceinline__ void b_update_block(const float* __restrict__ Bold, float* __restrict__ Bnew, const float* __restrict__ stats,
                      const float* __restrict__ HHt, CovMeta meta, int KP, float eps)
 {
     for (int i = 0; i < meta.n_cov; ++i) {
@@ -1148,8 +1197,7 @@ void b_update_kernel(const float* __restrict__ Bold, float* __restrict__ Bnew, c
 
 // loss_finalize (one block): row = [total, recon, pred_1..pred_C] in float64, main.py:726-753 with
 // recon = ||X||^2 - 2 <XH^T, W> + <W^TW, HH^T>  (all three terms belong to the same (W, H)).
-__global__ __launch_bounds__(256)
-void loss_finalize_kernel(const double* __restrict__ dotpart, int ndot, const float* __restrict__ WtW,
+__device__ __forceinline__ void loss_finalize_block(const double* __restrict__ dotpart, int ndot, const float* __restrict__ WtW,
                           const float* __restrict__ HHt, const float* __restrict__ stats, CovMeta meta,
                           int nstat, int KP, const double* __restrict__ lam64, double* __restrict__ row)
 {
@@ -1177,6 +1225,44 @@ void loss_finalize_kernel(const double* __restrict__ dotpart, int ndot, const fl
         row[0] = total;
         row[1] = recon;
     }
+}
+
+__global__ __launch_bounds__(256)
+void b_update_kernel(const float* __restrict__ Bold, float* __restrict__ Bnew, const float* __restrict__ stats,
+                     const float* __restrict__ HHt, CovMeta meta, int KP, float eps)
+{
+    b_update_block(Bold, Bnew, stats, HHt, meta, KP, eps);
+}
+
+__global__ __launch_bounds__(256)
+void loss_finalize_kernel(const double* __restrict__ dotpart, int ndot, const float* __restrict__ WtW,
+                          const float* __restrict__ HHt, const float* __restrict__ stats, CovMeta meta,
+                          int nstat, int KP, const double* __restrict__ lam64, double* __restrict__ row)
+{
+    loss_finalize_block(dotpart, ndot, WtW, HHt, stats, meta, nstat, KP, lam64, row);
+}
+
+// The middle of phase 2 in ONE launch: after the W update three things depend on its result and on nothing else of each
+// other -- the partial blocks of W^TW (gram), the pending loss row (needs the <XH^T, W_old> partials and the OLD W^TW, which
+// reduce_many only overwrites afterwards) and the B updates.  Blocks [0, gram_blocks) run the gram, the next two the tails.
+struct Phase2Mid {
+    int gram_blocks, do_loss, do_b;
+    const double* dotpart; int ndot; const float* WtW; const float* HHt; const float* stats; int nstat; const double* lam64; double* row;
+    const float* Bold; float* Bnew; float eps;
+};
+
+template <int KT>
+__global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
+void phase2_mid_kernel(const float* __restrict__ W, float* __restrict__ part, int R, int rows_per_wave, Phase2Mid a, CovMeta meta)
+{
+    constexpr int KP = 32 * KT;
+    const int b = blockIdx.x;
+    if (b < a.gram_blocks) { gram_block<KT>(W, part, R, rows_per_wave, b); return; }
+    if (b == a.gram_blocks) {
+        if (a.do_loss) loss_finalize_block(a.dotpart, a.ndot, a.WtW, a.HHt, a.stats, meta, a.nstat, KP, a.lam64, a.row);
+        return;
+    }
+    if (a.do_b) b_update_block(a.Bold, a.Bnew, a.stats, a.HHt, meta, KP, a.eps);
 }
 
 // ----------------------------------------------------------------------------------------------
