@@ -732,16 +732,16 @@ static int phase1(alpine_ctx* c, const CellView& v)
 {
     int rc;
     const int KP = c->KP;
-    if (c->n_cov > 0) {
-        int max_k = 1, max_c = 1;
-        for (int i = 0; i < c->n_cov; ++i) { max_k = std::max(max_k, c->cov_k[i]); max_c = std::max(max_c, c->cov_lev[i]); }
-        const int max_ct = std::min(HS_CT, max_c);
-        const size_t hs_bytes = sizeof(double) * HS_CELLS + sizeof(float) * ((size_t)(max_k + max_ct) * HS_CELLS + (size_t)max_ct * max_k);
-        hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hs_bytes, c->stream, v.H, v.Y, c->B[c->bcur], c->meta,
-                           c->statPart, v.N, v.Np, KP, (float)c->eps, c->nstat, max_k, max_ct);
-        HIPCHK(c, hipGetLastError());
-    }
-    if (c->unfused_mid) {            // A/B: every reduction in its own launch
+    int max_k = 1, max_c = 1;
+    for (int i = 0; i < c->n_cov; ++i) { max_k = std::max(max_k, c->cov_k[i]); max_c = std::max(max_c, c->cov_lev[i]); }
+    const int max_ct = std::min(HS_CT, max_c);
+    const size_t hs_bytes = hstats_group_bytes(max_k, max_ct);
+    if (c->unfused_mid) {            // A/B: every small kernel and every reduction in its own launch
+        if (c->n_cov > 0) {
+            hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hs_bytes, c->stream, v.H, v.Y, c->B[c->bcur], c->meta,
+                               c->statPart, v.N, v.Np, KP, (float)c->eps, c->nstat, max_k, max_ct);
+            HIPCHK(c, hipGetLastError());
+        }
         hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,
                            v.statBlocks, c->nstat, c->xnorm2);
         HIPCHK(c, hipGetLastError());
@@ -751,10 +751,14 @@ static int phase1(alpine_ctx* c, const CellView& v)
         if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
         return launch_reduce_pieces(c, c->piecesA, c->red, (int)c->Gp, v.gA);
     }
-    // partial blocks of H H^T, then the sweep, then ONE launch for the three reductions that close phase 1
+    // ONE launch for the two small kernels that read only the old H (H H^T partial blocks, covariate statistics), then
+    // the sweep, then ONE launch for the three reductions that close phase 1
     const int rpw = gram_rows_per_wave(v.Np, c->n_cu);
     const int gblocks = (int)((v.Np + 4 * rpw - 1) / (4 * rpw));
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(gram_kernel<KT_>, dim3(gblocks), dim3(256), 0, c->stream, v.H, c->gramPart, (int)v.Np, rpw));
+    const int stat_blocks2 = c->n_cov > 0 ? (v.statBlocks + 1) / 2 : 0;
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL(phase1_open_kernel<KT_>, dim3(gblocks + stat_blocks2), dim3(256), 2 * hs_bytes, c->stream, v.H, c->gramPart,
+                                           (int)v.Np, rpw, gblocks, v.Y, c->B[c->bcur], c->meta, c->statPart, v.N, v.Np, (float)c->eps, c->nstat,
+                                           max_k, max_ct, v.statBlocks));
     HIPCHK(c, hipGetLastError());
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
     if ((rc = launch_sweep(c, v.gA, v.Xng, v.H, c->piecesA, 0))) return rc;

@@ -439,21 +439,30 @@ __device__ __forceinline__ float lane_bcast(float v, int src)   // src must be a
 constexpr int HS_CELLS = 128;
 constexpr int HS_CT = 16;
 
-__global__ __launch_bounds__(HS_CELLS)
-void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, const float* __restrict__ B,
-                   CovMeta meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat, int max_k, int max_ct)
+__host__ __device__ inline size_t hstats_group_bytes(int max_k, int max_ct)
+{
+    size_t b = sizeof(double) * HS_CELLS + sizeof(float) * ((size_t)(max_k + max_ct) * HS_CELLS + (size_t)max_ct * max_k);
+    return (b + 15) & ~(size_t)15;
+}
+
+// One group = 128 threads = 128 cells; a block may hold several groups (`group` = index inside the block, `gblock` = the
+// group's global index = row of `part`): every group has its own slice of the dynamic LDS, barriers are block-wide (all
+// groups run the same trip counts).
+__device__ __forceinline__ void hstats_group(const float* __restrict__ H, const float* __restrict__ Y, const float* __restrict__ B,
+                                             const CovMeta& meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat,
+                                             int max_k, int max_ct, unsigned char* __restrict__ smem_base, int group, int64_t gblock)
 {
     // dynamic LDS sized for THIS model (max_k = largest k_i, max_ct = min(HS_CT, largest C_i)): a few KB instead of the
     // 45 KB of worst-case static arrays, so that all blocks of a shard are resident at once and hide each other's latency
-    extern __shared__ __attribute__((aligned(16))) unsigned char hs_smem[];
-    double* lred = reinterpret_cast<double*>(hs_smem);                                   // [HS_CELLS]
+    const size_t group_bytes = hstats_group_bytes(max_k, max_ct);
+    double* lred = reinterpret_cast<double*>(smem_base + (size_t)group * group_bytes);  // [HS_CELLS]
     float (*hbuf)[HS_CELLS] = reinterpret_cast<float (*)[HS_CELLS]>(lred + HS_CELLS);    // [max_k][HS_CELLS]
     float (*zbuf)[HS_CELLS] = hbuf + max_k;                                              // [max_ct][HS_CELLS]
     float* Blf = reinterpret_cast<float*>(zbuf + max_ct);                                // [max_ct][max_k]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t n = (int64_t)blockIdx.x * HS_CELLS + t;
+    const int t = threadIdx.x & (HS_CELLS - 1), lane = t & 63, wave = t >> 6;
+    const int64_t n = gblock * HS_CELLS + t;
     const bool valid = n < N;
-    float* out = part + (int64_t)blockIdx.x * nstat;
+    float* out = part + gblock * nstat;
 
     for (int i = 0; i < meta.n_cov; ++i) {
         const int ki = meta.k[i], Ci = meta.lev[i], off = meta.off[i];
@@ -510,6 +519,34 @@ void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, con
             so[Ci * ki + ki + 1] = (float)(lred[0] - (double)hi);
         }
     }
+}
+
+__global__ __launch_bounds__(HS_CELLS)
+void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, const float* __restrict__ B,
+                   CovMeta meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat, int max_k, int max_ct)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char hs_smem[];
+    hstats_group(H, Y, B, meta, part, N, Np, KP, eps, nstat, max_k, max_ct, hs_smem, 0, blockIdx.x);
+}
+
+// The two small kernels that open phase 1 (both read only the old H) in ONE launch: blocks [0, gram_blocks) compute the
+// partial blocks of H H^T, the rest the per-covariate statistics, two 128-cell groups per 256-thread block.
+template <int KT>
+__global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
+void phase1_open_kernel(const float* __restrict__ H, float* __restrict__ gram_part, int R, int rows_per_wave, int gram_blocks,
+                        const float* __restrict__ Y, const float* __restrict__ B, CovMeta meta, float* __restrict__ stat_part,
+                        int N, int64_t Np, float eps, int nstat, int max_k, int max_ct, int stat_groups)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char hs_smem[];
+    constexpr int KP = 32 * KT;
+    const int b = blockIdx.x;
+    if (b < gram_blocks) { gram_block<KT>(H, gram_part, R, rows_per_wave, b); return; }
+    const int group = threadIdx.x >> 7;
+    int64_t gblock = (int64_t)(b - gram_blocks) * 2 + group;
+    // a block whose second group lies past the last cell still walks the same barriers: it works on the last valid
+    // group's cells again and writes the same values to the same row
+    if (gblock >= stat_groups) gblock = stat_groups - 1;
+    hstats_group(H, Y, B, meta, stat_part, N, Np, KP, eps, nstat, max_k, max_ct, hs_smem, group, gblock);
 }
 
 // stats[j] = sum over blocks of part[blk][j] in float64; kind[j]: 0 plain, 1 = hi word of a (hi,lo) pair
