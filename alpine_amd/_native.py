@@ -12,10 +12,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libalpine_hip.so")
+# tools/ may point at the diagnostics build (libalpine_hip_diag.so: timing-only ablations compiled in) -- the product never does
+if os.environ.get("ALPINE_HIP_LIBRARY"):
+    LIB_PATH = os.path.abspath(os.environ["ALPINE_HIP_LIBRARY"])
 
 LOSS_KL, LOSS_FROBENIUS = 0, 1
 X_CELLS_BY_GENES, X_GENES_BY_CELLS = 0, 1
-KERNEL_SWEEP_XHT, KERNEL_SWEEP_WTX = 0, 1
+KERNEL_SWEEP_XHT, KERNEL_SWEEP_WTX, KERNEL_ALLREDUCE = 0, 1, 2
+COMM_ID_BYTES = 128
+ERR_RCCL = -6
 FLAG_TRANSFORM_ONLY, FLAG_X_BF16, FLAG_USE_ALS, FLAG_X_SPLIT, FLAG_X3_PRODUCTS = 1, 2, 4, 8, 16
 BUF_REDUCE_BLOCK, BUF_WTW, BUF_W, BUF_H, BUF_X_GN, BUF_X_NG = 0, 1, 2, 3, 4, 5
 
@@ -25,6 +30,7 @@ EXPORTS = [
     "alpine_set_factors", "alpine_get_factors", "alpine_iter_begin", "alpine_iter_end", "alpine_reduce_block",
     "alpine_als_begin", "alpine_als_group_begin", "alpine_als_group_end", "alpine_reduce_block_hht", "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_get_kernel_time", "alpine_read_buffer",
+    "alpine_comm_get_unique_id", "alpine_comm_init_rank", "alpine_comm_destroy", "alpine_comm_all_reduce", "alpine_iter",
 ]
 
 
@@ -106,6 +112,11 @@ def load() -> C.CDLL:
     lib.alpine_set_profiling.argtypes = [p, i32]
     lib.alpine_get_kernel_time.argtypes = [p, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.alpine_read_buffer.argtypes = [p, i32, i64, i64, p]
+    lib.alpine_comm_get_unique_id.argtypes = [p]
+    lib.alpine_comm_init_rank.argtypes = [p, p, i32, i32]
+    lib.alpine_comm_destroy.argtypes = [p]
+    lib.alpine_comm_all_reduce.argtypes = [p, i64, i64]
+    lib.alpine_iter.argtypes = [p, i32]
     for name in EXPORTS:
         if name not in ("alpine_reduce_block_floats", "alpine_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -151,6 +162,7 @@ class NativeShard:
         self.n_genes, self.n_cells, self.n_cov = n_genes, n_cells, n_cov
         self.cov_components, self.cov_levels = list(cov_components), list(cov_levels)
         self.k_total = n_components + sum(cov_components)
+        self.comm_ranks, self.comm_rank = 1, 0
         rc = self._lib.alpine_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             msg = self._lib.alpine_last_error(None).decode()
@@ -223,6 +235,28 @@ class NativeShard:
     def iter_end(self, update: bool = True):
         self._chk(self._lib.alpine_iter_end(self._h, 1 if update else 0))
 
+    def iter(self, update: bool = True):
+        """begin + [all-reduce when a communicator is attached] + end"""
+        self._chk(self._lib.alpine_iter(self._h, 1 if update else 0))
+
+    # -- multi-GPU (RCCL inside the library)
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        """Collective: every rank of the communicator calls this with the id rank 0 got from ``comm_unique_id()``."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._chk(self._lib.alpine_comm_init_rank(self._h, C.cast(buf, C.c_void_p), nranks, rank))
+        self.comm_ranks, self.comm_rank = nranks, rank
+
+    def comm_destroy(self):
+        self._chk(self._lib.alpine_comm_destroy(self._h))
+        self.comm_ranks, self.comm_rank = 1, 0
+
+    def comm_all_reduce(self, offset: int = 0, n: Optional[int] = None):
+        if n is None:
+            n = self.reduce_block()[1] - offset
+        self._chk(self._lib.alpine_comm_all_reduce(self._h, offset, n))
+
     def reduce_block(self):
         ptr, n = C.c_void_p(), C.c_int64()
         self._chk(self._lib.alpine_reduce_block(self._h, C.byref(ptr), C.byref(n)))
@@ -233,7 +267,7 @@ class NativeShard:
 
     def batch_step(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
-        self._chk(self._lib.alpine_batch_step(self._h, idx.ctypes.data, idx.size))
+        self._chk(self._lib.alpine_batch_step(self._h, idx.ctypes.data if idx.size else None, idx.size))
 
     def epoch_loss(self):
         self._chk(self._lib.alpine_epoch_loss(self._h))
@@ -302,6 +336,16 @@ class NativeShard:
         out = np.empty(n, dtype=np.float32)
         self._chk(self._lib.alpine_read_buffer(self._h, which, offset, n, out.ctypes.data))
         return out
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: rank 0 calls this and hands the bytes to every rank."""
+    lib = load()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.alpine_comm_get_unique_id(C.cast(buf, C.c_void_p))
+    if rc != 0:
+        raise AlpineNativeError(rc, lib.alpine_last_error(None).decode())
+    return buf.raw
 
 
 def reduce_block_floats(n_genes: int, n_cells: int, n_components: int, cov_components: Sequence[int],

@@ -10,6 +10,9 @@ SRC = os.path.join(HERE, "csrc", "alpine_hip.hip")
 DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))] + \
        [os.path.join(os.path.dirname(HERE), "include", "alpine_hip.h")]
 LIB = os.path.join(HERE, "libalpine_hip.so")
+# diagnostics build (-DALPINE_DIAGNOSTICS): the timing-only ablations of tools/ (wrong results by design) exist only here
+LIB_DIAG = os.path.join(HERE, "libalpine_hip_diag.so")
+ROCM_LIB = "/opt/rocm/lib"
 
 
 def hipcc_path() -> str:
@@ -19,24 +22,28 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: libalpine_hip.so cannot be built")
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB):
+def is_stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not is_stale():
-        return LIB
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), diagnostics: bool = False) -> str:
+    """hipcc -> libalpine_hip.so (links libamdhip64 and librccl; in a torch process both resolve to the copies torch has
+    already loaded, same sonames).  diagnostics=True builds libalpine_hip_diag.so with the ablation knobs compiled in."""
+    lib = LIB_DIAG if diagnostics else LIB
+    if not force and not is_stale(lib):
+        return lib
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB, SRC]
+           "-Wall", "-Wno-unused-function", *(("-DALPINE_DIAGNOSTICS",) if diagnostics else ()), *extra_flags,
+           "-o", lib, SRC, f"-L{ROCM_LIB}", "-lrccl", f"-Wl,-rpath,{ROCM_LIB}"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     import sys
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, diagnostics="--diag" in sys.argv))

@@ -5,6 +5,8 @@
 #include "kernels_bf16.hpp"
 #include "kernels_x3.hpp"
 
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -73,6 +75,7 @@ struct alpine_ctx {
     int gramBlocksH = 0, gramBlocksW = 0;
     float* statPart = nullptr;
     int statBlocks = 0;
+    int64_t statPart_cap = 0, gramPart_cap = 0;        // capacities in blocks (a mini-batch view may be larger than the shard)
     int* kind = nullptr;
     double *dotpart = nullptr, *lam_dev = nullptr, *loss_dev = nullptr, *f64part = nullptr;
     int ndot = 0;
@@ -88,11 +91,17 @@ struct alpine_ctx {
     std::vector<bool> y_set;
     size_t bytes = 0;
     std::string err;
-    // timing-only ablation (env ALPINE_HIP_ABLATE_STRIDE0=1): the sweeps re-read row 0 of X (served from cache) -> wrong
-    // results, prices the HBM stream against the MFMA pipeline.  Never set in tests or bench.
+    // A/B knobs that change the launch structure, never the results; read from the environment ONCE, in alpine_create
     bool unfused_mid = false;         // env ALPINE_HIP_UNFUSED_MID=1: separate loss_finalize / b_update / gram launches (A/B)
-    bool ablate_stride0 = false;
-    bool ablate_panel = false;        // env ALPINE_HIP_ABLATE_PANEL=1: bf16 sweeps re-read panel stage 0 (timing only, wrong results)
+    // timing-only ablations that produce WRONG results: compiled only into the diagnostics build (-DALPINE_DIAGNOSTICS,
+    // libalpine_hip_diag.so, used by tools/); the production library ignores these environment variables
+    bool ablate_stride0 = false;      // ALPINE_HIP_ABLATE_STRIDE0=1: the sweeps re-read row 0 of X (prices the HBM stream)
+    bool ablate_panel = false;        // ALPINE_HIP_ABLATE_PANEL=1: bf16 sweeps re-read panel stage 0
+    bool ablate_flush = false;        // ALPINE_HIP_ABLATE_FLUSH=1: x3 sweeps skip the accumulator flush
+    int x3_ablate = 0;                // ALPINE_HIP_X3_ABLATE=1|2|3
+    // multi-GPU: communicator over the shards of the cell axis (alpine_comm_init_rank); collectives run on `stream`
+    ncclComm_t comm = nullptr;
+    int comm_ranks = 1, comm_rank = 0;
     bool transform_only = false;
     bool use_als = false;
     bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
@@ -100,7 +109,7 @@ struct alpine_ctx {
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ALPINE_KERNEL_COUNT];
-    size_t ev_used[ALPINE_KERNEL_COUNT] = {0, 0};
+    size_t ev_used[ALPINE_KERNEL_COUNT] = {};
 };
 
 static int fail(alpine_ctx* c, int code, const char* fmt, ...)
@@ -120,6 +129,13 @@ static int fail(alpine_ctx* c, int code, const char* fmt, ...)
         if (e_ != hipSuccess)                                                                     \
             return fail((c), e_ == hipErrorOutOfMemory ? ALPINE_ERR_OOM : ALPINE_ERR_HIP,         \
                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define NCCLCHK(c, expr)                                                                          \
+    do {                                                                                          \
+        ncclResult_t r_ = (expr);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return fail((c), ALPINE_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
 #define DISPATCH_KT(kt, CALL)                  \
@@ -239,9 +255,13 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, ALPINE_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     c->n_cu = prop.multiProcessorCount;
-    if (const char* e = std::getenv("ALPINE_HIP_ABLATE_STRIDE0")) c->ablate_stride0 = (e[0] == '1');
     c->unfused_mid = getenv_is("ALPINE_HIP_UNFUSED_MID", '1');
-    if (const char* e = std::getenv("ALPINE_HIP_ABLATE_PANEL")) c->ablate_panel = (e[0] == '1');
+#ifdef ALPINE_DIAGNOSTICS
+    c->ablate_stride0 = getenv_is("ALPINE_HIP_ABLATE_STRIDE0", '1');
+    c->ablate_panel = getenv_is("ALPINE_HIP_ABLATE_PANEL", '1');
+    c->ablate_flush = getenv_is("ALPINE_HIP_ABLATE_FLUSH", '1');
+    if (const char* e = std::getenv("ALPINE_HIP_X3_ABLATE")) c->x3_ablate = std::atoi(e);
+#endif
     if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
     if (const char* e = std::getenv("ALPINE_HIP_H_UPDATE")) c->h_update_valu = (std::strcmp(e, "valu") == 0);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
@@ -265,7 +285,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
     // sweeps
     // bf16 sweeps with K <= 64: 8-wave workgroups (1024-column tiles, one per CU); everything else 4 waves x 512 columns
-    c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;
+    c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;   // A/B of the workgroup shape, same results
     const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
     c->slots = slots;
     const int sweep_bf = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
@@ -311,12 +331,20 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     const int rows_per_gram_block = 4 * GR_ROWS_PER_WAVE;
     c->gramBlocksH = (int)((Np + rows_per_gram_block - 1) / rows_per_gram_block);
     c->gramBlocksW = (int)((Gp + rows_per_gram_block - 1) / rows_per_gram_block);
+    // a mini-batch view holds up to batch_capacity cells, which may exceed the shard (draws with replacement, or a
+    // global batch whose cells all fall into this rank's block): the per-block partial buffers are sized for both
+    const int64_t view_cells_max = std::max<int64_t>(c->N, cfg->batch_capacity);
     {
         auto nblk = [&](int64_t R) { const int rpw = gram_rows_per_wave(R, c->n_cu); return (R + 4 * rpw - 1) / (4 * rpw); };
-        ALLOC(c, c->gramPart, float, (int64_t)std::max(nblk(Np), nblk(Gp)) * KP * KP);
+        c->gramPart_cap = std::max(std::max(nblk(Np), nblk(Gp)), nblk(round_up(view_cells_max, 128)));
+        // nblk() is not monotone in R (rows per wave grow with R): cover every view size up to the maximum
+        for (int64_t R = 128; R <= round_up(view_cells_max, 128) && R <= (int64_t)4 * GR_ROWS_PER_WAVE * 4 * c->n_cu; R += 128)
+            c->gramPart_cap = std::max(c->gramPart_cap, nblk(R));
+        ALLOC(c, c->gramPart, float, c->gramPart_cap * KP * KP);
     }
     c->statBlocks = (int)((c->N + HS_CELLS - 1) / HS_CELLS);
-    ALLOC(c, c->statPart, float, (int64_t)c->statBlocks * std::max(1, c->nstat));
+    c->statPart_cap = (view_cells_max + HS_CELLS - 1) / HS_CELLS;
+    ALLOC(c, c->statPart, float, c->statPart_cap * std::max(1, c->nstat));
     ALLOC(c, c->kind, int, kind.size());
     HIPCHK(c, hipMemcpyAsync(c->kind, kind.data(), sizeof(int) * kind.size(), hipMemcpyHostToDevice, c->stream));
     c->ndot = (int)((c->G + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4)) * 4;
@@ -366,6 +394,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
                     c->WtW, c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -679,17 +708,17 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
     if (c->x3) {
         SweepGeom gx = g;
-        if (getenv_is("ALPINE_HIP_ABLATE_FLUSH", '1')) gx.panel_fixed = 2;
+        if (c->ablate_flush) gx.panel_fixed = 2;
         switch (c->KT) {
             case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
-            case 2: {
-                const char* ab = std::getenv("ALPINE_HIP_X3_ABLATE");      // timing-only diagnostics (wrong results)
-                const int abl = ab ? std::atoi(ab) : 0;
-                if (abl == 1) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else if (abl == 2) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else if (abl == 3) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-            } break;
+            case 2:
+#ifdef ALPINE_DIAGNOSTICS
+                if (c->x3_ablate == 1) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
+                if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
+                if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
+#endif
+                hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
             default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
         }
@@ -982,6 +1011,81 @@ extern "C" int alpine_als_group_end(alpine_ctx* c, int grp)
     return als_group_update(c, c->full, grp);
 }
 
+// ---------------------------------------------------------------------------------- multi-GPU (RCCL over xGMI)
+// One process per GPU, one ctx per process; the cell axis is sharded over the ranks of the communicator.  The only data
+// that crosses shards is the reduce block (one sum all-reduce per iteration), enqueued on the ctx stream
+// right behind the kernels that fill it -- no host synchronisation, no second stream.
+extern "C" int alpine_comm_get_unique_id(void* id_out)
+{
+    if (!id_out) return fail(nullptr, ALPINE_ERR_BAD_ARG, "id_out is NULL");
+    static_assert(sizeof(ncclUniqueId) == ALPINE_COMM_ID_BYTES, "ALPINE_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+    ncclUniqueId id;
+    NCCLCHK(nullptr, ncclGetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int alpine_comm_init_rank(alpine_ctx* c, const void* id, int nranks, int rank)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, ALPINE_ERR_BAD_ARG, "bad communicator arguments (nranks %d, rank %d)", nranks, rank);
+    if (c->comm) return fail(c, ALPINE_ERR_STATE, "the ctx already has a communicator");
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, uid, rank));
+    c->comm_ranks = nranks; c->comm_rank = rank;
+    return 0;
+}
+
+extern "C" int alpine_comm_destroy(alpine_ctx* c)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!c->comm) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    NCCLCHK(c, ncclCommDestroy(c->comm));
+    c->comm = nullptr; c->comm_ranks = 1; c->comm_rank = 0;
+    return 0;
+}
+
+// in-place sum all-reduce of red[off, off + n) on the ctx stream; a no-op without a communicator
+static int comm_all_reduce(alpine_ctx* c, int64_t off, int64_t n)
+{
+    if (!c->comm) return 0;
+    int rc;
+    if ((rc = prof_begin(c, ALPINE_KERNEL_ALLREDUCE))) return rc;
+    NCCLCHK(c, ncclAllReduce(c->red + off, c->red + off, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
+    return prof_end(c, ALPINE_KERNEL_ALLREDUCE);
+}
+
+extern "C" int alpine_comm_all_reduce(alpine_ctx* c, int64_t offset_floats, int64_t n_floats)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!c->comm) return fail(c, ALPINE_ERR_STATE, "no communicator attached (alpine_comm_init_rank)");
+    if (offset_floats < 0 || n_floats < 0 || offset_floats + n_floats > c->red_floats)
+        return fail(c, ALPINE_ERR_BAD_ARG, "range outside the reduce block (%lld floats)", (long long)c->red_floats);
+    HIPCHK(c, hipSetDevice(c->device));
+    return comm_all_reduce(c, offset_floats, n_floats);
+}
+
+// One whole iteration INCLUDING its exchanges when a communicator is attached (identical to alpine_iter_begin +
+// alpine_iter_end without one): begin -> all-reduce -> end; block-coordinate branch: + the K x K slot after every group.
+extern "C" int alpine_iter(alpine_ctx* c, int update)
+{
+    int rc = alpine_iter_begin(c);
+    if (rc) return rc;
+    if ((rc = comm_all_reduce(c, 0, c->red_floats))) return rc;
+    if (!update || !c->use_als || !c->comm) return alpine_iter_end(c, update);
+    if ((rc = alpine_als_begin(c))) return rc;
+    for (int grp = 0; grp <= c->n_cov; ++grp) {
+        if ((rc = alpine_als_group_begin(c, grp))) return rc;
+        if (grp > 0 && (rc = comm_all_reduce(c, c->red_hht, (int64_t)c->KP * c->KP))) return rc;
+        if ((rc = alpine_als_group_end(c, grp))) return rc;
+    }
+    return 0;
+}
+
 // where the K x K H H^T slot sits inside the reduce block (for the per-group exchange of the use_als branch)
 extern "C" int alpine_reduce_block_hht(alpine_ctx* c, int64_t* offset_floats, int64_t* n_floats)
 {
@@ -1041,6 +1145,11 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
         return fail(c, ALPINE_ERR_STATE, "internal: batch view needs more sweep pieces than were allocated");
     v.statBlocks = (int)((n + HS_CELLS - 1) / HS_CELLS);
     v.gramBlocksH = (int)((Bp + 4 * GR_ROWS_PER_WAVE - 1) / (4 * GR_ROWS_PER_WAVE));
+    {
+        const int rpw = gram_rows_per_wave(Bp, c->n_cu);
+        if (v.statBlocks > c->statPart_cap || (Bp + 4 * rpw - 1) / (4 * rpw) > c->gramPart_cap)
+            return fail(c, ALPINE_ERR_STATE, "internal: batch view needs more partial blocks than were allocated");
+    }
     if ((rc = phase1(c, v))) return rc;
     c->batch_open = true;
     return 0;
@@ -1076,9 +1185,12 @@ extern "C" int alpine_batch_end(alpine_ctx* c)
 
 extern "C" int alpine_batch_step(alpine_ctx* c, const int64_t* idx, int64_t n)
 {
-    if (c && n <= 0) return fail(c, ALPINE_ERR_BAD_ARG, "batch of %lld cells outside the ctx's batch_capacity %lld", (long long)n, (long long)c->batch_cap);
-    const int rc = alpine_batch_begin(c, idx, n);
-    return rc ? rc : alpine_batch_end(c);
+    // single shard: an empty batch is a caller error; with a communicator a rank may hold none of the batch's cells
+    if (c && (n < 0 || (n == 0 && !c->comm))) return fail(c, ALPINE_ERR_BAD_ARG, "batch of %lld cells outside the ctx's batch_capacity %lld", (long long)n, (long long)c->batch_cap);
+    int rc = alpine_batch_begin(c, idx, n);
+    if (rc) return rc;
+    if ((rc = comm_all_reduce(c, 0, c->red_floats))) return rc;
+    return alpine_batch_end(c);
 }
 
 // Loss row of the CURRENT factors over all cells (main.py:666 after the batches of an epoch): full-view phase 1,
@@ -1105,8 +1217,10 @@ extern "C" int alpine_epoch_loss_end(alpine_ctx* c)
 
 extern "C" int alpine_epoch_loss(alpine_ctx* c)
 {
-    const int rc = alpine_epoch_loss_begin(c);
-    return rc ? rc : alpine_epoch_loss_end(c);
+    int rc = alpine_epoch_loss_begin(c);
+    if (rc) return rc;
+    if ((rc = comm_all_reduce(c, 0, c->red_floats))) return rc;
+    return alpine_epoch_loss_end(c);
 }
 
 extern "C" int alpine_transform(alpine_ctx* c, int n_iter)
@@ -1141,14 +1255,9 @@ extern "C" int alpine_run(alpine_ctx* c, int n_iters, int with_loss)
     if (rc) return rc;
     if (n_iters < 0) return fail(c, ALPINE_ERR_BAD_ARG, "n_iters must be >= 0");
     c->loss_enabled = with_loss != 0;
-    for (int it = 0; it < n_iters; ++it) {
-        if ((rc = alpine_iter_begin(c))) return rc;
-        if ((rc = alpine_iter_end(c, 1))) return rc;
-    }
-    if (with_loss && c->pending_loss) {
-        if ((rc = alpine_iter_begin(c))) return rc;
-        if ((rc = alpine_iter_end(c, 0))) return rc;
-    }
+    for (int it = 0; it < n_iters; ++it)
+        if ((rc = alpine_iter(c, 1))) return rc;
+    if (with_loss && c->pending_loss && (rc = alpine_iter(c, 0))) return rc;
     c->loss_enabled = true;
     return 0;
 }

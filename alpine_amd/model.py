@@ -21,7 +21,8 @@ import torch
 from . import _native
 from .anndata_compat import is_anndata
 from .encoder import FeatureEncoders
-from .sharded import ShardedLoop, TorchDistComm, shard_bounds
+from .sharded import (NativeComm, ShardedLoop, TorchDistComm, all_ranks_ok, attach_native_comm, check_shardable,
+                      native_comm_possible, shard_bounds)
 
 Float32Array = np.ndarray
 
@@ -66,6 +67,7 @@ class ALPINE:
         random_state: int = 42,
         shard_cells: Union[bool, str] = False,
         x_dtype: str = "x3",
+        shard_comm: str = "auto",
     ):
         self.n_components = n_components
         self.n_covariate_components = n_covariate_components
@@ -89,6 +91,12 @@ class ALPINE:
         if shard_cells not in (False, True, "local"):
             raise ValueError("shard_cells must be False, True or 'local'")
         self.shard_cells = shard_cells
+        # carrier of the per-iteration all-reduce when shard_cells is on: "native" = the library's own RCCL communicator
+        # (ncclAllReduce enqueued by the C loop itself), "torch" = torch.distributed.all_reduce on the process group's
+        # backend, "auto" = native when every rank owns a distinct GPU, else torch (e.g. gloo with ranks sharing a GPU)
+        if shard_comm not in ("auto", "native", "torch"):
+            raise ValueError("shard_comm must be 'auto', 'native' or 'torch'")
+        self.shard_comm = shard_comm
         # extension: storage / matrix-pipe mode of the two sweeps (the reference has float32 only).
         #   "x3" (default)  X float32 in HBM; every product is formed from the exact bf16 planes of both factors on the
         #                   bf16 matrix pipe (six plane products, float32 accumulate): float32-grade results for ANY X at
@@ -225,6 +233,8 @@ class ALPINE:
             N_total = sum(n for n, _ in sizes)
             c1 = c0 + sizes[rank][0]
         else:
+            if sharded:
+                check_shardable(N_total, world)        # same error on every rank, before any collective
             c0, c1 = shard_bounds(N_total, world, rank)
             row0 = c0
         n_loc = c1 - c0
@@ -271,30 +281,59 @@ class ALPINE:
                 raise
             return e
 
+        eng, create_err = None, None
         try:
-            eng = make_engine(x_dtype)
-        except _native.AlpineNativeError as err:
-            # "auto" only: X has more than 16 significant bits somewhere -> the pre-split storage does not apply; keep X in
-            # float32 and split it inside the sweeps instead
-            if not (self.x_dtype == "auto" and x_dtype == "split" and err.code == -5):
+            try:
+                eng = make_engine(x_dtype)
+            except _native.AlpineNativeError as err:
+                # "auto" only: X has more than 16 significant bits somewhere -> the pre-split storage does not apply; keep X
+                # in float32 and split it inside the sweeps instead.  Sharded: the choice must be the same on every rank
+                # (a rank-local exception would leave the peers blocked in the first all-reduce), so it is agreed on below.
+                if not (self.x_dtype == "auto" and x_dtype == "split" and err.code == -5):
+                    raise
+                if not sharded:
+                    x_dtype = "x3"
+                    eng = make_engine(x_dtype)
+        except Exception as e:          # noqa: BLE001
+            if not sharded:
                 raise
-            x_dtype = "x3"
-            eng = make_engine(x_dtype)
+            create_err = e
+        if sharded:
+            all_ranks_ok(dist, create_err is None, "engine creation", create_err)
+            if self.x_dtype == "auto" and x_dtype == "split":
+                fits = [None] * world
+                dist.all_gather_object(fits, eng is not None)
+                if not all(fits):                       # some shard's X is not bf16-plane exact: all ranks take x3
+                    if eng is not None:
+                        eng.close()
+                    x_dtype = "x3"
+                    eng = make_engine(x_dtype)
         self.x_dtype_used = x_dtype
         try:
+            comm = None
+            if sharded:
+                mode = self.shard_comm
+                if mode == "auto":
+                    mode = "native" if native_comm_possible(dist, dev_index) else "torch"
+                if mode == "native":
+                    attach_native_comm(eng, dist)
+                    comm = NativeComm(eng)
+                else:
+                    comm = TorchDistComm(block)
+                self.shard_comm_used = mode
             for i, y in enumerate(Y):
                 eng.upload_Y(i, np.ascontiguousarray(y[row0:row0 + n_loc].T))
             eng.set_factors(W0, H0, B0, h_col0=c0)
             if kw.get("batch_capacity", 0) > 0:
                 if sharded:
                     with torch.cuda.device(dev_index), torch.cuda.stream(stream):
-                        self._run_epochs(eng, Y, N_total, n_iter, comm=TorchDistComm(block), c0=c0, c1=c1,
+                        self._run_epochs(eng, Y, N_total, n_iter, comm=comm, c0=c0, c1=c1,
                                          gather_labels=dist if local_input else None)
                 else:
                     self._run_epochs(eng, Y, N_total, n_iter)
             elif sharded:
                 with torch.cuda.device(dev_index), torch.cuda.stream(stream):
-                    ShardedLoop(eng, TorchDistComm(block), als_groups=(len(cov_levels) + 1 if self.use_als else 0)).run(n_iter, with_loss=True)
+                    ShardedLoop(eng, comm, als_groups=(len(cov_levels) + 1 if self.use_als else 0)).run(n_iter, with_loss=True)
             elif self.verbose:
                 # main.py:490-494, :669-671: tqdm bar with the objective loss.  The loop runs asynchronously on the device,
                 # so the bar advances in chunks (one host sync per chunk instead of one per iteration).

@@ -7,12 +7,23 @@ sums into one contiguous float32 block in ``iter_begin``; after the all-reduce e
 the global sums and ``iter_end`` updates the replicated W, B and the local columns of H with no
 further communication.  The reference has no counterpart (single device, main.py:70).
 
+Two carriers for that one collective:
+
+* **native** (default when every rank owns its own GPU): the library holds an RCCL communicator
+  (``alpine_comm_init_rank``) and its composite entry points (``alpine_run``, ``alpine_iter``,
+  ``alpine_batch_step``, ``alpine_epoch_loss``) enqueue ``ncclAllReduce`` on the ctx stream themselves --
+  the per-iteration loop is plain C, torch only carries the 128-byte unique id at start-up
+  (``attach_native_comm``).
+* **torch** (``TorchDistComm``): ``torch.distributed.all_reduce`` on a tensor that aliases the reduce
+  block, between the split entry points (``iter_begin`` / ``iter_end``): any backend, e.g. gloo for the
+  rehearsal where several ranks share one GPU, which RCCL refuses.
+
 ``ShardedLoop`` only orchestrates; the engine is ``_native.NativeShard`` in production.  Tests
 drive the same loop with a CPU engine over gloo to cover the N>1 logic without GPUs.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 
 def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -25,6 +36,48 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
             return n_total
         return min(n_total, ((n_total * r) // world + 4) // 8 * 8)
     return cut(rank), cut(rank + 1)
+
+
+def check_shardable(n_total: int, world: int) -> None:
+    """Raise the SAME error on every rank when some rank would get no cells (interior cuts are rounded to multiples of
+    8, so small N over many ranks leaves empty blocks): a rank-local failure before a collective would hang the peers."""
+    empty = [r for r in range(world) if shard_bounds(n_total, world, r)[0] >= shard_bounds(n_total, world, r)[1]]
+    if empty:
+        raise ValueError(f"cannot shard {n_total} cells over {world} ranks: rank(s) {empty} would hold no cells "
+                         f"(need at least 8 cells per rank)")
+
+
+def all_ranks_ok(dist, ok: bool, what: str, err: Optional[BaseException] = None) -> None:
+    """Agree on a rank-local outcome before the next collective: every rank raises if any rank failed."""
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, (bool(ok), "" if err is None else f"{type(err).__name__}: {err}"))
+    bad = [(r, m) for r, (f, m) in enumerate(flags) if not f]
+    if bad:
+        if err is not None:
+            raise err
+        raise RuntimeError(f"{what} failed on rank(s) " + ", ".join(f"{r} ({m})" for r, m in bad))
+
+
+def native_comm_possible(dist, device_index: int) -> bool:
+    """RCCL needs one distinct GPU per rank (it refuses two ranks on one device); single node assumed."""
+    devs = [None] * dist.get_world_size()
+    dist.all_gather_object(devs, int(device_index))
+    return len(set(devs)) == len(devs)
+
+
+def attach_native_comm(engine, dist, group=None) -> None:
+    """Give ``engine`` an RCCL communicator over the ranks of the torch.distributed group: rank 0 draws the unique id
+    through the library, torch broadcasts its 128 bytes (control plane only), every rank joins.  Collective."""
+    from . import _native
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [_native.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    err = None
+    try:
+        engine.comm_init(box[0], world, rank)
+    except Exception as e:          # noqa: BLE001 -- agree with the peers before raising
+        err = e
+    all_ranks_ok(dist, err is None, "alpine_comm_init_rank", err)
 
 
 class TorchDistComm:
@@ -46,6 +99,22 @@ class TorchDistComm:
         self._dist.all_reduce(self.block[offset:offset + n], op=self._dist.ReduceOp.SUM, group=self.group)
 
 
+class NativeComm:
+    """The library's own communicator behind the same two calls as ``TorchDistComm`` (for callers that keep the split
+    begin / end entry points, e.g. the mini-batch epochs); ``ShardedLoop`` skips it and calls ``engine.run`` directly."""
+
+    native = True
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def all_reduce(self) -> None:
+        self.engine.comm_all_reduce(0, None)
+
+    def all_reduce_slice(self, offset: int, n: int) -> None:
+        self.engine.comm_all_reduce(offset, n)
+
+
 class ShardedLoop:
     def __init__(self, engine, comm, als_groups: int = 0):
         """``als_groups`` > 0: block-coordinate branch (use_als) with that many component groups (covariates + 1); the
@@ -53,9 +122,13 @@ class ShardedLoop:
         self.engine = engine
         self.comm = comm
         self.als_groups = als_groups
-        self._hht = engine.reduce_block_hht() if als_groups > 0 else None
+        self.native = bool(getattr(comm, "native", False))
+        self._hht = engine.reduce_block_hht() if als_groups > 0 and not self.native else None
 
     def step(self, update: bool = True) -> None:
+        if self.native:
+            self.engine.iter(update)          # begin, ncclAllReduce on the ctx stream, end (+ group exchanges): all in C
+            return
         self.engine.iter_begin()
         self.comm.all_reduce()
         if not update or self.als_groups == 0:
@@ -69,6 +142,9 @@ class ShardedLoop:
             self.engine.als_group_end(grp)
 
     def run(self, n_iters: int, with_loss: bool = True) -> None:
+        if self.native:
+            self.engine.run(n_iters, with_loss=with_loss)
+            return
         for _ in range(n_iters):
             self.step(True)
         if with_loss and n_iters > 0:

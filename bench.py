@@ -15,8 +15,13 @@ Sweep modes (--dtype; all but "bf16" give float32-grade results, see DESIGN.md 4
   split         X pre-split into 1-2 exact bf16 planes at ingest (integer counts): HBM-bound at 2 B per element
   bf16          operands ROUNDED to bf16 (BASELINE config 5), tolerance reported by the tests
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N worker processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; the per-iteration all-reduce of the reduce block is RCCL over xGMI, enqueued by the library's
+own C loop (alpine_comm_init_rank / alpine_run; --comm torch keeps torch.distributed.all_reduce on the nccl backend
+instead).  `python bench.py --gpus N` without a launcher spawns the N workers itself (fresh child processes, started
+before this process touches a GPU), relays rank 0's JSON line and fails if any worker fails or the watchdog expires.
 
 Rank 0 prints ONE JSON line (see the repo's driver contract) with two extra objects:
   roofline     -- the dominant kernel (the streaming sweep, 2 launches/iteration): algorithmic bytes (or, for
@@ -40,6 +45,7 @@ sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBPS = 8000.0
+FULLSIG_SCALE = 0.3712345          # multiplies the synthetic counts for the full-significand legs (every float32 then needs all three bf16 planes)
 
 WORKLOADS = {
     # name: genes, cells, K_u, k_i, alpha, orth, l1
@@ -61,7 +67,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra (non-headline) split / bf16 measurements at N=1")
     ap.add_argument("--no-loss", action="store_true", help="updates only (secondary number)")
-    ap.add_argument("--cpu-sample-cells", type=int, default=12000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=0,
+                    help="cells of the CPU-baseline sample; 0 = 50000 (BASELINE config 2's size, ~25 GB RSS) when the host has the RAM, else 12000")
+    ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
+                    help="N > 1: carrier of the all-reduce -- native = RCCL inside libalpine_hip (default), torch = torch.distributed")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 self-launch: watchdog over the workers, seconds")
     ap.add_argument("--dtype", default="x3", choices=["f32", "bf16", "split", "x3"],
                     help="x3: float32 X, products from exact bf16 planes in the sweep (float32-grade, any X); f32: float32 MFMA; "
                          "split: X pre-split into exact bf16 planes (float32-grade; needs bf16-exact X such as counts); "
@@ -84,14 +94,35 @@ def labels_onehot(n_cells: int, seed: int) -> np.ndarray:
 def cpu_baseline(wl: dict, sample_cells: int, full_cells: int) -> dict:
     """Oracle (faithful restatement of main.py:500-667 incl. randperm gather and per-iteration loss)
     on torch-CPU, all host cores, on `sample_cells` cells of the same workload."""
+    import resource
     import torch
     from alpine_amd.datasets import synth_counts_host
     from oracle import alpine_oracle as orc
     G, ku, kcov = wl["genes"], wl["ku"], wl["kcov"]
+    mem_avail_gb = None
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    mem_avail_gb = int(line.split()[1]) / 2**20
+    except OSError:
+        pass
+    if sample_cells <= 0:
+        # SURVEY.md 8d: the reference needs ~6.2 x the bytes of X as RSS (24 GB at 20k x 50k); take BASELINE config 2's
+        # size when the host has clearly more than that free, else the small sample
+        need_gb = 6.5 * 4.0 * G * 50000 / 2**30 + 8.0
+        big = mem_avail_gb is not None and mem_avail_gb > 2.0 * need_gb
+        sample_cells = 50000 if big else 12000
+        branch = (f"auto: MemAvailable {mem_avail_gb:.0f} GiB {'>' if big else '<='} 2 x {need_gb:.0f} GiB -> {sample_cells} cells"
+                  if mem_avail_gb is not None else f"auto: MemAvailable unknown -> {sample_cells} cells")
+    else:
+        branch = f"--cpu-sample-cells {sample_cells}"
+    sample_cells = min(sample_cells, full_cells)
     X = synth_counts_host(sample_cells, G, rank=ku, seed=0)
     Ys = [labels_onehot(sample_cells, seed=1 + i).T for i in range(len(kcov))]       # N x C
     p = orc.OracleParams(n_components=ku, n_covariate_components=list(kcov), lam=[1e3] * len(kcov),
                          orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"])
+    t_leg = time.perf_counter()
     s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
     orc.fit_faithful(p, s, 1)                       # warm-up
     n_it = 3
@@ -124,7 +155,9 @@ def cpu_baseline(wl: dict, sample_cells: int, full_cells: int) -> dict:
                    f"per-iteration loss), {G} genes x {sample_cells} cells of the same synthetic workload, {n_it} timed "
                    f"iterations after 1 warm-up = {dt:.1f} s; measured {it_s_sample:.4f} it/s on the sample, scaled linearly "
                    f"in cells to {full_cells} (conservative: the reference scales super-linearly, BASELINE.md section 2)"),
-        "measured_sample_it_per_s": it_s_sample,
+        "measured_sample_it_per_s": it_s_sample, "sample_cells": sample_cells, "sample_branch": branch,
+        "peak_rss_GiB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20, 1), "mem_available_GiB_before": mem_avail_gb,
+        "leg_seconds": time.perf_counter() - t_leg,
         "fused_port_value": it_s_fused * sample_cells / full_cells,      # oracle.fit_fused, same sample and scaling
         "fused_port_measured_sample_it_per_s": it_s_fused,
         "host_cpu": cpu_model, "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
@@ -152,22 +185,97 @@ def pmc_traffic(workload: str, world: int, kp: int, dtype: str = "f32"):
     return best
 
 
+def launch_workers(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N fresh worker processes (one per GPU) BEFORE this process
+    makes any GPU call, relay rank 0's JSON line, fail loudly if a worker fails or the watchdog expires.  No exec of
+    this process, no kill-by-pattern: only the PIDs started here are ever signalled."""
+    import socket
+    import subprocess
+    import threading
+    import torch
+    n = args.gpus
+    rehearsal = os.environ.get("ALPINE_BENCH_REHEARSAL_ONE_GPU") == "1"
+    have = torch.cuda.device_count()            # counting devices does not initialise the GPU runtime
+    if have < n and not rehearsal:
+        print(f"bench.py --gpus {n}: only {have} GPU(s) visible (ALPINE_BENCH_REHEARSAL_ONE_GPU=1 rehearses N ranks on one "
+              f"GPU over gloo)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    procs, lines = [], []
+
+    def pump(stream, keep):
+        for line in stream:
+            if keep and line.lstrip().startswith("{"):
+                lines.append(line)
+            else:
+                sys.stderr.write(line)
+        stream.close()
+
+    threads = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True)
+        procs.append(p)
+        t = threading.Thread(target=pump, args=(p.stdout, r == 0), daemon=True)
+        t.start()
+        threads.append(t)
+    deadline = time.monotonic() + args.launch_timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc = bad[0][1] if bad[0][1] > 0 else 1
+            print(f"bench.py: worker rank {bad[0][0]} exited with {bad[0][1]}; stopping the others", file=sys.stderr)
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            print(f"bench.py: watchdog: workers still running after {args.launch_timeout:.0f} s; stopping them", file=sys.stderr)
+            rc = 124
+            break
+        time.sleep(0.2)
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    for t in threads:
+        t.join(timeout=5)
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[0])
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args))
     import torch
     import torch.distributed as dist
     from alpine_amd import _native
     from alpine_amd.datasets import synth_counts_device_chunks
     from alpine_amd.model import draw_initial_factors
-    from alpine_amd.sharded import ShardedLoop, TorchDistComm, shard_bounds
+    from alpine_amd.sharded import NativeComm, ShardedLoop, TorchDistComm, attach_native_comm, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-        args.gpus = world
+    args.gpus = world                  # under a launcher the environment decides
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     # rehearsal knob for a one-GPU box: all ranks share device 0 and gloo carries the (device) reduce block;
@@ -207,8 +315,11 @@ def main():
     W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], levels)
     Ys = [np.ascontiguousarray(labels_onehot(N, seed=1 + i)[:, c0:c1]) for i in range(len(kcov))]
 
-    def measure(dtype: str) -> dict:
+    comm_state = {"carrier": None, "note": None}
+
+    def measure(dtype: str, x_scale: float = None) -> dict:
         """Build the resident state for one storage mode, run `warmup` untimed and `steps` timed iterations."""
+        x_scale = args.x_scale if x_scale is None else x_scale
         kw = dict(n_genes=G, n_cells=n_loc, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
                   orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], eps=1e-6,
                   loss_type="kl-divergence", device_id=local_rank, split_a=args.split_a, split_b=args.split_b, x_dtype=dtype)
@@ -223,8 +334,8 @@ def main():
             # synthetic input, generated on the device in cell chunks (never on the host)
             t_gen = time.perf_counter()
             for off, chunk in synth_counts_device_chunks(n_loc, G, rank=ku, seed=0, device=dev, chunk_cells=8192, cell_offset=c0):
-                if args.x_scale != 1.0:
-                    chunk = (chunk * args.x_scale).contiguous()
+                if x_scale != 1.0:
+                    chunk = (chunk * x_scale).contiguous()
                 torch.cuda.synchronize()
                 eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
                 eng.synchronize()
@@ -238,22 +349,37 @@ def main():
             info = eng.info()
             comm = None
             if world > 1:
-                class TimedComm(TorchDistComm):
-                    """all-reduce bracketed by events on the engine's stream: the time an iteration spends between the
-                    end of its phase-1 kernels and the arrival of the reduced block (transfer + waiting for the slowest rank)."""
-                    def __init__(self, blk):
-                        super().__init__(blk)
-                        self.pairs, self.on = [], False
+                # carrier of the per-iteration all-reduce: the library's own RCCL communicator (default) or torch.distributed
+                want = args.comm
+                if want == "auto":
+                    want = "torch" if rehearsal else "native"       # RCCL refuses several ranks on one GPU
+                if want == "native":
+                    try:
+                        attach_native_comm(eng, dist)
+                        comm = NativeComm(eng)
+                        comm_state["carrier"] = "native: ncclAllReduce enqueued by libalpine_hip (alpine_run) on the ctx stream"
+                    except Exception as e:          # noqa: BLE001 -- every rank raised together (all_ranks_ok): fall back together
+                        if args.comm == "native":
+                            raise
+                        comm_state["note"] = f"native communicator failed ({type(e).__name__}: {e}); fell back to torch.distributed"
+                if comm is None:
+                    class TimedComm(TorchDistComm):
+                        """all-reduce bracketed by events on the engine's stream: the time an iteration spends between the
+                        end of its phase-1 kernels and the arrival of the reduced block (transfer + waiting for the slowest rank)."""
+                        def __init__(self, blk):
+                            super().__init__(blk)
+                            self.pairs, self.on = [], False
 
-                    def all_reduce(self):
-                        if not self.on:
-                            return super().all_reduce()
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        super().all_reduce()
-                        e1.record()
-                        self.pairs.append((e0, e1))
-                comm = TimedComm(block)
+                        def all_reduce(self):
+                            if not self.on:
+                                return super().all_reduce()
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            super().all_reduce()
+                            e1.record()
+                            self.pairs.append((e0, e1))
+                    comm = TimedComm(block)
+                    comm_state["carrier"] = f"torch.distributed.all_reduce ({dist.get_backend()}) on the ctx stream"
             loop = ShardedLoop(eng, comm) if world > 1 else None
 
             def run(n):
@@ -273,7 +399,7 @@ def main():
             fence()
             eng.reset_losses()
             eng.set_profiling(True)
-            if comm is not None:
+            if comm is not None and hasattr(comm, "on"):
                 comm.on = True
             t0 = time.perf_counter()
             run(args.steps)
@@ -286,9 +412,12 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             ar_ms = None
-            if comm is not None:
+            if comm is not None and hasattr(comm, "on"):
                 comm.on = False
                 ar_ms = float(np.mean([a.elapsed_time(b) for a, b in comm.pairs])) if comm.pairs else None
+            elif comm is not None:
+                ms_c, n_c = eng.kernel_time(_native.KERNEL_ALLREDUCE)       # hipEvents around ncclAllReduce inside the library
+                ar_ms = ms_c / n_c if n_c else None
             ms_a, n_a = eng.kernel_time(_native.KERNEL_SWEEP_XHT)
             ms_b, n_b = eng.kernel_time(_native.KERNEL_SWEEP_WTX)
             losses = eng.losses()
@@ -306,7 +435,8 @@ def main():
             eng.close()
             del block
             torch.cuda.empty_cache()
-        return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen, dt_noloss=dt_noloss, ar_ms=ar_ms)
+        return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen, dt_noloss=dt_noloss,
+                    ar_ms=ar_ms, x_scale=x_scale)
 
     DTYPE_LABEL = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate",
                    "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)",
@@ -345,21 +475,25 @@ def main():
     if world == 1 and not args.no_other_modes and not args.no_loss:
         # the same workload in the other storage modes (not the headline): exact bf16-plane split (float32-grade
         # results, applies because the synthetic counts are bf16-exact) and rounded bf16 operands (BASELINE config 5)
-        for dt_name in ("x3", "split", "bf16", "f32"):
-            if dt_name == args.dtype:
-                continue
+        # ... and the headline's and the float32 MFMA's sweeps on FULL-SIGNIFICAND data (the same matrix times 0.3712345:
+        # 24-bit significands, all three bf16 planes populated): throughput depends on the values on this chip
+        # (x3 skips zero planes of count data; the clock the chip holds under load depends on operand toggling)
+        legs = [(n, n, None) for n in ("x3", "split", "bf16", "f32") if n != args.dtype]
+        if args.x_scale == 1.0:
+            legs += [(f"{n}_fullsig", n, FULLSIG_SCALE) for n in ("x3", "f32")]
+        for key, dt_name, xs in legs:
             try:
-                om = measure(dt_name)
-                others[dt_name] = {
-                    "dtype": DTYPE_LABEL[dt_name], "value": args.steps / om["dt"], "unit": "iterations/s",
+                om = measure(dt_name, xs)
+                others[key] = {
+                    "dtype": DTYPE_LABEL[dt_name], "x_scale": om["x_scale"], "value": args.steps / om["dt"], "unit": "iterations/s",
                     "ms_per_step": 1e3 * om["dt"] / args.steps, "roofline": roofline(om),
                     "final_loss_row": om["losses"][-1].tolist() if len(om["losses"]) else None,
                     "final_total_loss_rel_diff_vs_headline": (abs(om["losses"][-1][0] - main_m["losses"][-1][0]) / abs(main_m["losses"][-1][0])
-                                                              if len(om["losses"]) and len(main_m["losses"]) else None),
+                                                              if xs is None and len(om["losses"]) and len(main_m["losses"]) else None),
                     "device_GiB": round(om["info"].device_bytes / 2**30, 2),
                 }
             except Exception as e:            # an optional leg must not take the headline down
-                others[dt_name] = {"error": f"{type(e).__name__}: {e}"}
+                others[key] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         dt, info, losses = main_m["dt"], main_m["info"], main_m["losses"]
@@ -380,14 +514,15 @@ def main():
             "roofline": roofline(main_m),
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
             "allreduce": ({"avg_ms_on_rank0": main_m["ar_ms"], "bytes": int(info.reduce_block_floats) * 4,
-                           "note": "events on the engine stream around dist.all_reduce: transfer + wait for the slowest rank"}
-                          if main_m.get("ar_ms") is not None else None),
+                           "carrier": comm_state["carrier"], "fallback_note": comm_state["note"],
+                           "note": "hipEvents on the ctx stream around the all-reduce: transfer + wait for the slowest rank"}
+                          if world > 1 else None),
             "updates_only_iterations_per_s": (args.steps / main_m["dt_noloss"]) if main_m.get("dt_noloss") else None,
             "setup_s": main_m["t_gen"],
             "other_modes": others or None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample_cells, N), N)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_cells, N)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -5,6 +5,12 @@
  *   gcc -O2 -Iinclude examples/fit_c.c -o examples/fit_c -Lalpine_amd -lalpine_hip -Wl,-rpath,$PWD/alpine_amd \
  *       -Wl,-rpath-link,/opt/rocm/lib
  *   examples/fit_c problem.bin result.bin
+ *   examples/fit_c --ranks R problem.bin result.bin     cell axis sharded over R GPUs (devices 0..R-1), one process each
+ *
+ * --ranks R: the parent forks R workers BEFORE anything touches a GPU.  Worker r takes the cells [N r/R, N (r+1)/R), rank 0
+ * draws the RCCL id (alpine_comm_get_unique_id) and publishes it through a file next to the result, every worker joins
+ * with alpine_comm_init_rank, and alpine_run then enqueues the one all-reduce per iteration itself -- the host loop is the
+ * same three calls as on one GPU.  Workers write result.bin.rank<r>; the parent splices the columns of H together.
  *
  * problem.bin (little endian): int32 {magic 0x414c5031, G, N, Ku, C, loss_type, flags, T, scale}, then per covariate
  * int32 {k_i, C_i}; float64 {orth_W, alpha_W, l1_ratio_W, eps}; float64 lam[C]; float32 X[N][G] (cells x genes);
@@ -14,23 +20,53 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include "alpine_hip.h"
 
 #define MAXC 16
 
 static void die(const char* what, alpine_ctx* ctx)
 {
-    fprintf(stderr, "fit_c: %s: %s\n", what, ctx ? alpine_last_error(ctx) : "(no ctx)");
+    fprintf(stderr, "fit_c: %s: %s\n", what, alpine_last_error(ctx));
     exit(1);
 }
 static void rd(void* p, size_t sz, size_t n, FILE* f) { if (fread(p, sz, n, f) != n) { fprintf(stderr, "fit_c: short read\n"); exit(2); } }
 static float* rdf(size_t n, FILE* f) { float* p = (float*)malloc(sizeof(float) * (n ? n : 1)); if (!p) exit(3); rd(p, sizeof(float), n, f); return p; }
 
-int main(int argc, char** argv)
+/* rank 0 writes the id to <base>.id.tmp and renames it (atomic); the others wait for <base>.id */
+static void exchange_id(const char* base, int rank, unsigned char* id)
 {
-    if (argc != 3) { fprintf(stderr, "usage: fit_c problem.bin result.bin\n"); return 2; }
-    FILE* f = fopen(argv[1], "rb");
-    if (!f) { perror(argv[1]); return 2; }
+    char path[4096], tmp[4096];
+    snprintf(path, sizeof path, "%s.id", base);
+    if (rank == 0) {
+        if (alpine_comm_get_unique_id(id)) die("alpine_comm_get_unique_id", NULL);
+        snprintf(tmp, sizeof tmp, "%s.id.tmp", base);
+        FILE* f = fopen(tmp, "wb");
+        if (!f || fwrite(id, 1, ALPINE_COMM_ID_BYTES, f) != ALPINE_COMM_ID_BYTES) { perror(tmp); exit(2); }
+        fclose(f);
+        if (rename(tmp, path)) { perror(path); exit(2); }
+        return;
+    }
+    for (int tries = 0; tries < 6000; ++tries) {            /* up to 60 s */
+        FILE* f = fopen(path, "rb");
+        if (f) {
+            const size_t n = fread(id, 1, ALPINE_COMM_ID_BYTES, f);
+            fclose(f);
+            if (n == ALPINE_COMM_ID_BYTES) return;
+        }
+        usleep(10000);
+    }
+    fprintf(stderr, "fit_c: rank %d never saw the communicator id\n", rank);
+    exit(2);
+}
+
+/* one shard: cells [c0, c1) of the problem on device `device`; nranks > 0 attaches a communicator */
+static int run_shard(const char* problem, const char* result, int rank, int nranks, int device)
+{
+    FILE* f = fopen(problem, "rb");
+    if (!f) { perror(problem); return 2; }
     int32_t hdr[9];
     rd(hdr, sizeof(int32_t), 9, f);
     if (hdr[0] != 0x414c5031) { fprintf(stderr, "fit_c: bad magic\n"); return 2; }
@@ -50,11 +86,13 @@ int main(int argc, char** argv)
     float* H = rdf((size_t)(K * N), f);
     for (int i = 0; i < C; ++i) B[i] = rdf((size_t)(lev[i] * k[i]), f);
     fclose(f);
+    const int R = nranks > 0 ? nranks : 1;
+    const int64_t c0 = N * rank / R, c1 = N * (rank + 1) / R, n = c1 - c0;
 
     alpine_config cfg = {0};
     cfg.struct_size = (int32_t)sizeof(cfg);
-    cfg.device_id = 0;
-    cfg.n_genes = G; cfg.n_cells = N;
+    cfg.device_id = device;
+    cfg.n_genes = G; cfg.n_cells = n;
     cfg.n_components = Ku; cfg.n_covariates = C;
     cfg.cov_components = k; cfg.cov_levels = lev; cfg.lam = lam;
     cfg.orth_W = reg[0]; cfg.alpha_W = reg[1]; cfg.l1_ratio_W = reg[2]; cfg.eps = reg[3];
@@ -63,13 +101,19 @@ int main(int argc, char** argv)
 
     alpine_ctx* ctx = NULL;
     if (alpine_create(&cfg, &ctx)) die("alpine_create", ctx);
-    if (alpine_upload_X_host(ctx, X, ALPINE_X_CELLS_BY_GENES, G, 0, N)) die("alpine_upload_X_host", ctx);
+    if (nranks > 0) {
+        unsigned char id[ALPINE_COMM_ID_BYTES];
+        exchange_id(result, rank, id);
+        if (alpine_comm_init_rank(ctx, id, nranks, rank)) die("alpine_comm_init_rank", ctx);
+    }
+    /* the shard's rows of X, columns of Y and H: pointers into the full arrays with the full leading dimensions */
+    if (alpine_upload_X_host(ctx, X + c0 * G, ALPINE_X_CELLS_BY_GENES, G, 0, n)) die("alpine_upload_X_host", ctx);
     if (alpine_finalize_X(ctx)) die("alpine_finalize_X", ctx);
-    for (int i = 0; i < C; ++i) if (alpine_upload_Y(ctx, i, Y[i], N)) die("alpine_upload_Y", ctx);
-    if (alpine_set_factors(ctx, W, H, N, (const float* const*)B)) die("alpine_set_factors", ctx);
-    if (alpine_run(ctx, T, 1)) die("alpine_run", ctx);
+    for (int i = 0; i < C; ++i) if (alpine_upload_Y(ctx, i, Y[i] + c0, N)) die("alpine_upload_Y", ctx);
+    if (alpine_set_factors(ctx, W, H + c0, N, (const float* const*)B)) die("alpine_set_factors", ctx);
+    if (alpine_run(ctx, T, 1)) die("alpine_run", ctx);          /* with a communicator: + one ncclAllReduce per iteration */
     if (scale && alpine_scale(ctx)) die("alpine_scale", ctx);
-    if (alpine_get_factors(ctx, W, H, N, B)) die("alpine_get_factors", ctx);
+    if (alpine_get_factors(ctx, W, H + c0, N, B)) die("alpine_get_factors", ctx);
     double* rows = (double*)malloc(sizeof(double) * (size_t)(T > 0 ? T : 1) * (size_t)(C + 2));
     int64_t n_rows = 0;
     if (alpine_get_losses(ctx, rows, T, &n_rows)) die("alpine_get_losses", ctx);
@@ -77,17 +121,90 @@ int main(int argc, char** argv)
     if (alpine_get_info(ctx, &info)) die("alpine_get_info", ctx);
     alpine_destroy(ctx);
 
-    FILE* o = fopen(argv[2], "wb");
-    if (!o) { perror(argv[2]); return 2; }
+    char path[4096];
+    if (nranks > 0) snprintf(path, sizeof path, "%s.rank%d", result, rank); else snprintf(path, sizeof path, "%s", result);
+    FILE* o = fopen(path, "wb");
+    if (!o) { perror(path); return 2; }
     int32_t n32 = (int32_t)n_rows;
     fwrite(&n32, sizeof(int32_t), 1, o);
     fwrite(rows, sizeof(double), (size_t)n_rows * (size_t)(C + 2), o);
     fwrite(W, sizeof(float), (size_t)(G * K), o);
-    fwrite(H, sizeof(float), (size_t)(K * N), o);
+    fwrite(H, sizeof(float), (size_t)(K * N), o);              /* K x N with this shard's columns filled in */
     for (int i = 0; i < C; ++i) fwrite(B[i], sizeof(float), (size_t)(lev[i] * k[i]), o);
     fclose(o);
-    printf("fit_c: G=%lld N=%lld K=%d (padded %d), %lld loss rows, last total loss %.9g, %.1f MiB on the device\n",
-           (long long)G, (long long)N, K, info.k_padded, (long long)n_rows, n_rows ? rows[(n_rows - 1) * (C + 2)] : 0.0,
-           (double)info.device_bytes / 1048576.0);
+    printf("fit_c[%d/%d]: G=%lld cells [%lld, %lld) of %lld, K=%d (padded %d), %lld loss rows, last total loss %.9g, %.1f MiB on device %d\n",
+           rank, R, (long long)G, (long long)c0, (long long)c1, (long long)N, K, info.k_padded, (long long)n_rows,
+           n_rows ? rows[(n_rows - 1) * (C + 2)] : 0.0, (double)info.device_bytes / 1048576.0, device);
     return 0;
+}
+
+/* result.bin = rank 0's file with the other ranks' columns of H spliced in (W, B, losses are replicated) */
+static int splice(const char* problem, const char* result, int R)
+{
+    FILE* f = fopen(problem, "rb");
+    if (!f) { perror(problem); return 2; }
+    int32_t hdr[9];
+    rd(hdr, sizeof(int32_t), 9, f);
+    const int64_t G = hdr[1], N = hdr[2];
+    const int C = hdr[4];
+    int K = hdr[3];
+    size_t nb = 0;
+    for (int i = 0; i < C; ++i) { int32_t kc[2]; rd(kc, sizeof(int32_t), 2, f); K += kc[0]; nb += (size_t)kc[0] * (size_t)kc[1]; }
+    fclose(f);
+    unsigned char* out = NULL; size_t out_sz = 0, h_off = 0;
+    for (int r = 0; r < R; ++r) {
+        char path[4096];
+        snprintf(path, sizeof path, "%s.rank%d", result, r);
+        FILE* g = fopen(path, "rb");
+        if (!g) { perror(path); return 2; }
+        int32_t n_rows;
+        rd(&n_rows, sizeof n_rows, 1, g);
+        const size_t sz = 4 + 8 * (size_t)n_rows * (size_t)(C + 2) + 4 * ((size_t)(G * K) + (size_t)K * (size_t)N + nb);
+        unsigned char* buf = (unsigned char*)malloc(sz);
+        if (!buf) return 3;
+        memcpy(buf, &n_rows, 4);
+        rd(buf + 4, 1, sz - 4, g);
+        fclose(g);
+        remove(path);
+        if (r == 0) { out = buf; out_sz = sz; h_off = 4 + 8 * (size_t)n_rows * (size_t)(C + 2) + 4 * (size_t)(G * K); continue; }
+        const int64_t c0 = N * r / R, c1 = N * (r + 1) / R;
+        for (int kk = 0; kk < K; ++kk)
+            memcpy(out + h_off + 4 * ((size_t)kk * (size_t)N + (size_t)c0), buf + h_off + 4 * ((size_t)kk * (size_t)N + (size_t)c0), 4 * (size_t)(c1 - c0));
+        free(buf);
+    }
+    FILE* o = fopen(result, "wb");
+    if (!o || fwrite(out, 1, out_sz, o) != out_sz) { perror(result); return 2; }
+    fclose(o);
+    char idp[4096];
+    snprintf(idp, sizeof idp, "%s.id", result);
+    remove(idp);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc == 3) return run_shard(argv[1], argv[2], 0, 0, 0);
+    if (argc != 5 || strcmp(argv[1], "--ranks") != 0 || atoi(argv[2]) < 1 || atoi(argv[2]) > 64) {
+        fprintf(stderr, "usage: fit_c [--ranks R] problem.bin result.bin\n");
+        return 2;
+    }
+    const int R = atoi(argv[2]);
+    char idp[4096];
+    snprintf(idp, sizeof idp, "%s.id", argv[4]);
+    remove(idp);                                           /* a stale id of an earlier run must not be picked up */
+    pid_t pids[64];
+    for (int r = 0; r < R; ++r) {                          /* fork BEFORE any GPU call: the parent never touches the device */
+        pids[r] = fork();
+        if (pids[r] < 0) { perror("fork"); return 2; }
+        if (pids[r] == 0) _exit(run_shard(argv[3], argv[4], r, R, r));
+    }
+    int bad = 0;
+    for (int r = 0; r < R; ++r) {
+        int st = 0;
+        if (waitpid(pids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            fprintf(stderr, "fit_c: rank %d failed\n", r);
+            bad = 1;
+        }
+    }
+    return bad ? 1 : splice(argv[3], argv[4], R);
 }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALPINE_HIP_ABI_VERSION 3
+#define ALPINE_HIP_ABI_VERSION 4
 
 typedef struct alpine_ctx alpine_ctx;
 
@@ -38,7 +38,8 @@ typedef enum {
     ALPINE_ERR_HIP = -2,
     ALPINE_ERR_OOM = -3,
     ALPINE_ERR_STATE = -4,     /* call made in the wrong order (e.g. run before X / factors set) */
-    ALPINE_ERR_UNSUPPORTED = -5
+    ALPINE_ERR_UNSUPPORTED = -5,
+    ALPINE_ERR_RCCL = -6       /* a collective or communicator call failed (text in alpine_last_error) */
 } alpine_status;
 
 enum { ALPINE_LOSS_KL = 0, ALPINE_LOSS_FROBENIUS = 1 };      /* main.py:57, :371 */
@@ -66,7 +67,8 @@ enum {
     /* float32 X in HBM (layout, ingest and memory exactly as without any storage flag), but the two sweeps form every
      * product x*p from the exact bf16 planes of x and p on the bf16 matrix pipe: the six plane products that carry
      * everything above 2^-24 |x p| are accumulated in float32 (kernels_x3.hpp).  No precondition on X; results agree
-     * with the float32-MFMA sweeps to float32 rounding.  Takes effect for K <= 64 (wider models keep the float32 MFMA). */
+     * with the float32-MFMA sweeps to float32 rounding.  All K <= 128: a wave owns 256 columns x K <= 64 or 128 columns x
+     * K <= 128 (256 accumulator registers either way).  Ignored together with ALPINE_FLAG_X_BF16 / ALPINE_FLAG_X_SPLIT. */
     ALPINE_FLAG_X3_PRODUCTS = 16
 };
 enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
@@ -162,6 +164,24 @@ int alpine_als_group_begin(alpine_ctx* ctx, int grp);
 int alpine_als_group_end(alpine_ctx* ctx, int grp);
 int alpine_reduce_block_hht(alpine_ctx* ctx, int64_t* offset_floats, int64_t* n_floats);
 
+/* Multi-GPU inside the library (the reference is single-device, main.py:70): one process per GPU, one
+ * ctx per process, the cell axis sharded over the ranks of an RCCL communicator.  Rank 0 calls alpine_comm_get_unique_id
+ * and hands the 128 bytes to every rank by any means (a file, MPI, torch.distributed ...); every rank then calls
+ * alpine_comm_init_rank on its ctx (collective: returns when all ranks have joined).  With a communicator attached the
+ * COMPOSITE entry points -- alpine_iter, alpine_run, alpine_batch_step, alpine_epoch_loss -- enqueue the sum all-reduce of
+ * the reduce block (ncclAllReduce over xGMI) on the ctx stream themselves, between their begin and end halves (the
+ * block-coordinate branch adds the K x K slot after every group); alpine_batch_step then accepts n == 0.  The split
+ * entry points (alpine_iter_begin / _end, ...) never communicate: they remain for callers who bring their own collective,
+ * or who call alpine_comm_all_reduce (in place, on a range of the reduce block) in between.  W, B are replicated, every
+ * rank ends with identical copies; H, X, Y stay local.  alpine_destroy also destroys the communicator. */
+#define ALPINE_COMM_ID_BYTES 128
+int alpine_comm_get_unique_id(void* id_out /* ALPINE_COMM_ID_BYTES bytes */);
+int alpine_comm_init_rank(alpine_ctx* ctx, const void* id, int nranks, int rank);
+int alpine_comm_destroy(alpine_ctx* ctx);
+int alpine_comm_all_reduce(alpine_ctx* ctx, int64_t offset_floats, int64_t n_floats);
+/* alpine_iter_begin + [all-reduce when a communicator is attached] + alpine_iter_end(update). */
+int alpine_iter(alpine_ctx* ctx, int update);
+
 /* Mini-batch fitting (main.py:509-521, :512-663; alpine/utils/sampling.py:58-71): the caller draws the epoch's index
  * stream exactly as the reference does (torch.randperm, or the weighted sampler with replacement) and feeds it one batch
  * at a time.  alpine_batch_step gathers the n cells idx[0..n) of the local shard into a contiguous view, runs the W, B
@@ -203,8 +223,9 @@ int alpine_synchronize(alpine_ctx* ctx);
  * Needs float32 storage of X (any ctx but the bf16 / split ones; a transform-only ctx works).  Synchronises. */
 int alpine_eval_recon_direct(alpine_ctx* ctx, double* out);
 
-/* Measurement: when enabled, hipEvents bracket every launch of the two streaming sweeps. */
-enum { ALPINE_KERNEL_SWEEP_XHT = 0, ALPINE_KERNEL_SWEEP_WTX = 1, ALPINE_KERNEL_COUNT = 2 };
+/* Measurement: when enabled, hipEvents bracket every launch of the two streaming sweeps and every all-reduce the
+ * library enqueues (the latter: transfer + waiting for the slowest rank). */
+enum { ALPINE_KERNEL_SWEEP_XHT = 0, ALPINE_KERNEL_SWEEP_WTX = 1, ALPINE_KERNEL_ALLREDUCE = 2, ALPINE_KERNEL_COUNT = 3 };
 int alpine_set_profiling(alpine_ctx* ctx, int enabled);
 int alpine_get_kernel_time(alpine_ctx* ctx, int which, double* total_ms, int64_t* launches);
 

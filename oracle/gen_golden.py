@@ -79,6 +79,13 @@ def make_case_inputs(case: dict):
     obs = {}
     for key, levels, nan_frac in case["covariates"]:
         obs[key] = _labels(rng, n, levels, nan_frac)
+    if case.get("skew_first"):
+        # the first covariate becomes: its first level on the first `skew_first` cells, its second level everywhere else (a
+        # rare, heavily weighted joint label that lives in the FIRST shard of a cell-sharded run)
+        key, levels, _ = case["covariates"][0]
+        lab = np.array([levels[1]] * n, dtype=object)
+        lab[:case["skew_first"]] = levels[0]
+        obs[key] = lab
     return X, pd.DataFrame(obs)
 
 
@@ -126,6 +133,12 @@ CASES = [
     dict(name="full_weighted", n_cells=96, n_genes=64, seed=12, T=10, fit_kwargs=dict(sampling_method="weighted"),
          covariates=[("cond", ["a", "b", "c"], 0.0)],
          params=dict(n_components=4, n_covariate_components=[2], lam=[10.0], loss_type="frobenius")),
+    # weighted sampling with a rare label confined to the first cells: in a 2-rank run rank 0 receives ~74 % of every
+    # epoch's draws, i.e. MORE cells than its shard holds (draws with replacement) -- the mini-batch view's partial-block
+    # buffers must be sized for the batch, not for the shard
+    dict(name="weighted_skew", n_cells=640, n_genes=64, seed=16, T=5, fit_kwargs=dict(sampling_method="weighted"), skew_first=32,
+         covariates=[("cond", ["rare", "common"], 0.0)],
+         params=dict(n_components=4, n_covariate_components=[2], lam=[1e3])),
     # block-coordinate branch (use_als=True, main.py:523-588)
     dict(name="als_kl", n_cells=96, n_genes=64, seed=13, T=20,
          covariates=[("cond", ["a", "b"], 0.0)],

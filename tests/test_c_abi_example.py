@@ -17,7 +17,7 @@ EXE = os.path.join(REPO, "examples", "fit_c")
 def build_example():
     from alpine_amd.build import build_library
     build_library()
-    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "examples", "fit_c.c"), "-o", EXE,
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-D_DEFAULT_SOURCE", "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "examples", "fit_c.c"), "-o", EXE,
            "-L" + os.path.join(REPO, "alpine_amd"), "-lalpine_hip", "-Wl,-rpath," + os.path.join(REPO, "alpine_amd"),
            "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
@@ -65,6 +65,8 @@ def test_c_example_builds_links_and_fails_loudly_without_gpu(tmp_path):
     exe = build_example()
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([exe, "--ranks", "0", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
     if torch.cuda.is_available():
         pytest.skip("GPU present: the no-GPU failure path is not reachable here")
     prob = tmp_path / "p.bin"
@@ -89,3 +91,23 @@ def test_c_example_reproduces_reference(name, flags, tmp_path):
     for b, bt in zip(Bs, c.BT):
         assert rel_fro(b, bt) < 2e-4
     assert_loss_rows_close(losses, c.loss_history, n_cells=c.X.shape[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kl_2cov_nan", "als_kl"])
+def test_c_example_ranks_mode_native_rccl(name, tmp_path):
+    """`fit_c --ranks 1`: the forked worker draws an RCCL id, joins a one-rank communicator and alpine_run enqueues the
+    all-reduce itself; the spliced result must be BITWISE the single-process result (a one-rank sum changes nothing)."""
+    exe = build_example()
+    c = load_case(name)
+    flags = 16 | (4 if c.params.get("use_als") else 0)
+    prob, res1, res2 = tmp_path / "p.bin", tmp_path / "r1.bin", tmp_path / "r2.bin"
+    write_problem(prob, c, flags)
+    r = subprocess.run([exe, str(prob), str(res1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "--ranks", "1", str(prob), str(res2)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(res1, "rb").read() == open(res2, "rb").read()
+    assert not os.path.exists(str(res2) + ".id") and not os.path.exists(str(res2) + ".rank0")
+    losses, W, H, Bs = read_result(res2, c)
+    assert rel_fro(W, c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4

@@ -34,4 +34,30 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in cb, key
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     # every storage mode ran on the same workload next to the headline
-    assert set(d["other_modes"]) == {"f32", "split", "bf16"} and all("error" not in v for v in d["other_modes"].values())
+    # ... plus the headline's and the float32 MFMA's sweeps on full-significand data (throughput is value-dependent)
+    assert set(d["other_modes"]) == {"f32", "split", "bf16", "x3_fullsig", "f32_fullsig"}
+    assert all("error" not in v for v in d["other_modes"].values()), d["other_modes"]
+    assert d["other_modes"]["x3_fullsig"]["x_scale"] != 1.0 and d["config"]["x_scale"] == 1.0
+    assert cb["sample_cells"] == 500 and cb["peak_rss_GiB"] > 0
+
+
+def test_bench_gpus_2_launches_its_own_workers():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's invocation): the parent starts two fresh worker
+    processes, relays rank 0's single JSON line and exits 0.  On a one-GPU box the rehearsal switch puts both ranks on
+    cuda:0 with gloo carrying the reduce block (RCCL refuses two ranks on one device); without it the launcher must refuse."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "4", "--warmup", "1"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+        assert r.returncode == 2 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+        env["ALPINE_BENCH_REHEARSAL_ONE_GPU"] = "1"
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["config"]["parallelism"] == "cells/2" and d["config"]["cells_per_gpu"] in (2496, 2504)
+    ar = d["allreduce"]
+    assert ar is not None and ar["avg_ms_on_rank0"] > 0 and ar["bytes"] > 0 and ar["carrier"]

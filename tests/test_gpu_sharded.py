@@ -103,11 +103,14 @@ def test_two_ranks_local_input(case_name, tmp_path):
         assert rel_fro(Ht, Ht1) < 2e-5
 
 
-@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", False), ("mb_weighted", True), ("full_weighted", True)])
+@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", False), ("mb_weighted", True), ("full_weighted", True),
+                                             ("weighted_skew", False)])
 def test_two_ranks_minibatch(case_name, local, tmp_path):
     """Mini-batch / weighted sampling sharded over two ranks: both draw the same global index stream, each takes the
     batch's cells that fall into its block (sometimes none), the reduce block is all-reduced between batch_begin and
-    batch_end.  Must reproduce the REFERENCE's stochastic run (same tolerances as the single-device mini-batch test)."""
+    batch_end.  Must reproduce the REFERENCE's stochastic run (same tolerances as the single-device mini-batch test).
+    weighted_skew: a rare, heavily weighted label lives in rank 0's block, so rank 0 receives ~470 of every epoch's 640 draws
+    -- more cells than its 320-cell shard holds and more 128-cell statistic blocks than the shard has."""
     import torch.multiprocessing as mp
     from _golden import assert_loss_rows_close, load_case, rel_fro
     world = 2
