@@ -71,11 +71,19 @@ struct alpine_ctx {
     float* red = nullptr;
     bool own_red = false;
     int64_t red_floats = 0, red_hht = 0, red_stats = 0;
-    float *WtW = nullptr, *gramPart = nullptr;
+    float *WtW = nullptr, *gramPart = nullptr;          // WtW = the CURRENT one of WtWbuf[2] (the fused phase 2 writes the other, then swaps)
+    float* WtWbuf[2] = {nullptr, nullptr};
+    bool fused_w = true;                               // env ALPINE_HIP_FUSED_W=0: W update and W^T W in separate launches (A/B)
     int gramBlocksH = 0, gramBlocksW = 0;
     float* statPart = nullptr;
     int statBlocks = 0;
     int64_t statPart_cap = 0, gramPart_cap = 0;        // capacities in blocks (a mini-batch view may be larger than the shard)
+    // fused tail of the H update (MU branch, whole shard): partial blocks of H H^T and covariate statistics of the UPDATED H,
+    // i.e. what the next phase 1 needs -> that phase 1 skips phase1_open_kernel while tail_valid
+    float *gramPartH = nullptr, *statPartH = nullptr;
+    int tail_blocks = 0;                               // grid of the fused H update (128 cells per block)
+    bool tail_valid = false;
+    bool no_tail = false;                              // env ALPINE_HIP_NO_TAIL=1: separate phase1_open_kernel every iteration (A/B)
     int* kind = nullptr;
     double *dotpart = nullptr, *lam_dev = nullptr, *loss_dev = nullptr, *f64part = nullptr;
     int ndot = 0;
@@ -85,8 +93,8 @@ struct alpine_ctx {
     int64_t stage_floats = 0;
     // state
     double xnorm2 = 0;
-    std::vector<char> x_seen;         // coarse coverage tracking of uploaded cell chunks
-    int64_t x_cells_uploaded = 0;
+    std::vector<std::pair<int64_t, int64_t>> x_cover;   // disjoint, sorted cell intervals [a, b) uploaded so far
+    bool x_plane2_dropped = false;    // split mode: alpine_finalize_X found the second plane all zero and freed it
     bool x_final = false, factors_set = false, pending_loss = false, loss_enabled = true;
     std::vector<bool> y_set;
     size_t bytes = 0;
@@ -256,6 +264,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         return fail(c, ALPINE_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     c->n_cu = prop.multiProcessorCount;
     c->unfused_mid = getenv_is("ALPINE_HIP_UNFUSED_MID", '1');
+    c->no_tail = getenv_is("ALPINE_HIP_NO_TAIL", '1') || c->unfused_mid;
+    c->fused_w = !getenv_is("ALPINE_HIP_FUSED_W", '0') && !c->unfused_mid;
 #ifdef ALPINE_DIAGNOSTICS
     c->ablate_stride0 = getenv_is("ALPINE_HIP_ABLATE_STRIDE0", '1');
     c->ablate_panel = getenv_is("ALPINE_HIP_ABLATE_PANEL", '1');
@@ -327,7 +337,9 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->red_floats = g.red_floats; c->red_hht = g.red_hht; c->red_stats = g.red_stats;
     if (cfg->reduce_block) { c->red = (float*)cfg->reduce_block; c->own_red = false; HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream)); }
     else { ALLOC(c, c->red, float, c->red_floats); c->own_red = true; }
-    ALLOC(c, c->WtW, float, KP * KP);
+    ALLOC(c, c->WtWbuf[0], float, KP * KP);
+    ALLOC(c, c->WtWbuf[1], float, KP * KP);
+    c->WtW = c->WtWbuf[0];
     const int rows_per_gram_block = 4 * GR_ROWS_PER_WAVE;
     c->gramBlocksH = (int)((Np + rows_per_gram_block - 1) / rows_per_gram_block);
     c->gramBlocksW = (int)((Gp + rows_per_gram_block - 1) / rows_per_gram_block);
@@ -337,6 +349,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     {
         auto nblk = [&](int64_t R) { const int rpw = gram_rows_per_wave(R, c->n_cu); return (R + 4 * rpw - 1) / (4 * rpw); };
         c->gramPart_cap = std::max(std::max(nblk(Np), nblk(Gp)), nblk(round_up(view_cells_max, 128)));
+        c->gramPart_cap = std::max<int64_t>(c->gramPart_cap, Gp / 128);       // the fused W update writes one block per 128 genes
         // nblk() is not monotone in R (rows per wave grow with R): cover every view size up to the maximum
         for (int64_t R = 128; R <= round_up(view_cells_max, 128) && R <= (int64_t)4 * GR_ROWS_PER_WAVE * 4 * c->n_cu; R += 128)
             c->gramPart_cap = std::max(c->gramPart_cap, nblk(R));
@@ -345,6 +358,12 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->statBlocks = (int)((c->N + HS_CELLS - 1) / HS_CELLS);
     c->statPart_cap = (view_cells_max + HS_CELLS - 1) / HS_CELLS;
     ALLOC(c, c->statPart, float, c->statPart_cap * std::max(1, c->nstat));
+    {
+        // fused tail: one partial H H^T block and one statistics row per 128-cell block of the H update (N x 2 KP bytes)
+        c->tail_blocks = (int)((c->N + HS_CELLS - 1) / HS_CELLS);
+        ALLOC(c, c->gramPartH, float, (int64_t)c->tail_blocks * KP * KP);
+        ALLOC(c, c->statPartH, float, (int64_t)c->tail_blocks * std::max(1, c->nstat));
+    }
     ALLOC(c, c->kind, int, kind.size());
     HIPCHK(c, hipMemcpyAsync(c->kind, kind.data(), sizeof(int) * kind.size(), hipMemcpyHostToDevice, c->stream));
     c->ndot = (int)((c->G + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4)) * 4;
@@ -358,7 +377,6 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->scale, float, KP);
     c->stage_floats = std::max<int64_t>((int64_t)1 << 26, std::max<int64_t>((int64_t)c->K * Np, Gp * (int64_t)KP));   // >= 256 MiB
     ALLOC(c, c->stage, float, c->stage_floats);
-    c->x_seen.assign((size_t)((c->N + 1023) / 1024), 0);
     c->full.Xgn = c->Xgn; c->full.Xng = c->Xng; c->full.H = c->H; c->full.Y = c->Y;
     c->full.N = c->N; c->full.Np = Np; c->full.gA = c->geomA; c->full.gB = c->geomB;
     c->full.statBlocks = c->statBlocks; c->full.gramBlocksH = c->gramBlocksH;
@@ -396,7 +414,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtW, c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -473,12 +491,28 @@ static int check_x_args(alpine_ctx* c, const float* p, int layout, int64_t ld, i
     if (!p) return fail(c, ALPINE_ERR_BAD_ARG, "X pointer is NULL");
     if (layout != ALPINE_X_CELLS_BY_GENES && layout != ALPINE_X_GENES_BY_CELLS) return fail(c, ALPINE_ERR_BAD_ARG, "unknown X layout %d", layout);
     if (cell0 < 0 || n <= 0 || cell0 + n > c->N) return fail(c, ALPINE_ERR_BAD_ARG, "cell range [%lld, %lld) outside the shard's %d cells", (long long)cell0, (long long)(cell0 + n), c->N);
+    if (c->x_plane2_dropped)
+        return fail(c, ALPINE_ERR_STATE, "X was finalised as ONE exact bf16 plane and the second plane's memory was released: create a new ctx to upload other data");
     const int64_t min_ld = layout == ALPINE_X_CELLS_BY_GENES ? c->G : n;
     if (ld < min_ld) return fail(c, ALPINE_ERR_BAD_ARG, "ld %lld smaller than the row length %lld", (long long)ld, (long long)min_ld);
     return 0;
 }
 
-static void mark_x(alpine_ctx* c, int64_t n) { c->x_cells_uploaded += n; c->x_final = false; }
+// coverage of the shard's cells by the uploaded chunks: union of intervals (re-uploading a chunk overwrites it and
+// counts once); alpine_finalize_X requires the union to be exactly [0, N)
+static void mark_x(alpine_ctx* c, int64_t cell0, int64_t n)
+{
+    auto& v = c->x_cover;
+    v.emplace_back(cell0, cell0 + n);
+    std::sort(v.begin(), v.end());
+    size_t o = 0;
+    for (size_t i = 1; i < v.size(); ++i) {
+        if (v[i].first <= v[o].second) v[o].second = std::max(v[o].second, v[i].second);
+        else v[++o] = v[i];
+    }
+    v.resize(o + 1);
+    c->x_final = false;
+}
 
 extern "C" int alpine_upload_X_device(alpine_ctx* c, const float* dev, int layout, int64_t ld, int64_t cell0, int64_t n)
 {
@@ -487,7 +521,7 @@ extern "C" int alpine_upload_X_device(alpine_ctx* c, const float* dev, int layou
     HIPCHK(c, hipSetDevice(c->device));
     rc = upload_x_dev(c, dev, layout, ld, cell0, n);
     if (rc) return rc;
-    mark_x(c, n);
+    mark_x(c, cell0, n);
     return 0;
 }
 
@@ -498,7 +532,7 @@ extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout
     HIPCHK(c, hipSetDevice(c->device));
     const int G = c->G;
     if (layout == ALPINE_X_CELLS_BY_GENES) {
-        const int64_t step = std::max<int64_t>(1, c->stage_floats / G);
+        const int64_t step = std::max<int64_t>(8, c->stage_floats / G / 8 * 8);   // multiple of 8 cells: the bf16 paths pack 8 cells per granule
         for (int64_t r = 0; r < n; r += step) {
             const int64_t m = std::min(step, n - r);
             HIPCHK(c, hipStreamSynchronize(c->stream));         // staging buffer is reused
@@ -507,7 +541,7 @@ extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout
             if (rc) return rc;
         }
     } else {
-        const int64_t step = std::max<int64_t>(1, c->stage_floats / G);      // cells per piece
+        const int64_t step = std::max<int64_t>(8, c->stage_floats / G / 8 * 8);      // cells per piece (multiple of 8)
         for (int64_t r = 0; r < n; r += step) {
             const int64_t m = std::min(step, n - r);
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -517,7 +551,7 @@ extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    mark_x(c, n);
+    mark_x(c, cell0, n);
     return 0;
 }
 
@@ -535,7 +569,13 @@ static int sum_f64_partials(alpine_ctx* c, int n, double* out)
 extern "C" int alpine_finalize_X(alpine_ctx* c)
 {
     if (!c) return ALPINE_ERR_BAD_ARG;
-    if (c->x_cells_uploaded < c->N) return fail(c, ALPINE_ERR_STATE, "only %lld of %d cells of X were uploaded", (long long)c->x_cells_uploaded, c->N);
+    if (c->x_cover.size() != 1 || c->x_cover[0].first != 0 || c->x_cover[0].second != c->N) {
+        int64_t have = 0;
+        for (auto& iv : c->x_cover) have += iv.second - iv.first;
+        int64_t gap = 0;                                   // first cell that no chunk covered
+        for (auto& iv : c->x_cover) { if (iv.first > gap) break; gap = std::max(gap, iv.second); }
+        return fail(c, ALPINE_ERR_STATE, "only %lld of %d cells of X were uploaded (first missing cell: %lld)", (long long)have, c->N, (long long)gap);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t n4 = c->Gp * c->Np / (c->bf16 ? 8 : 4);
     const int blocks = (int)std::min<int64_t>(4096, (n4 + 255) / 256);
@@ -548,6 +588,7 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         if (c->npx == 1) {            // ... so give its memory back
             if (c->Xgn16b) { HIPCHK(c, hipFree(c->Xgn16b)); c->Xgn16b = nullptr; c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
             if (c->Xng16b) { HIPCHK(c, hipFree(c->Xng16b)); c->Xng16b = nullptr; if (!c->transform_only) c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
+            c->x_plane2_dropped = true;                      // further uploads would write plane 2 into freed memory: refused (check_x_args)
         }
     }
     if (c->bf16) hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, c->Xgn16,
@@ -570,6 +611,7 @@ extern "C" int alpine_upload_Y(alpine_ctx* c, int cov, const float* host, int64_
     HIPCHK(c, hipMemcpy2D(c->Y + (int64_t)c->meta.yoff[cov] * c->Np, sizeof(float) * c->Np, host, sizeof(float) * ld,
                           sizeof(float) * c->N, (size_t)c->cov_lev[cov], hipMemcpyHostToDevice));
     c->y_set[cov] = true;
+    c->tail_valid = false;
     return 0;
 }
 
@@ -605,6 +647,7 @@ extern "C" int alpine_set_factors(alpine_ctx* c, const float* W, const float* H,
     HIPCHK(c, hipGetLastError());
     c->factors_set = true;
     c->pending_loss = false;
+    c->tail_valid = false;
     return 0;
 }
 
@@ -780,26 +823,30 @@ static int phase1(alpine_ctx* c, const CellView& v)
         if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
         return launch_reduce_pieces(c, c->piecesA, c->red, (int)c->Gp, v.gA);
     }
-    // ONE launch for the two small kernels that read only the old H (H H^T partial blocks, covariate statistics), then
-    // the sweep, then ONE launch for the three reductions that close phase 1
+    // ONE launch for the two small kernels that read only the old H (H H^T partial blocks, covariate statistics) -- or none
+    // at all when the previous H update already produced them in its tail -- then the sweep, then ONE launch for the
+    // three reductions that close phase 1
+    const bool from_tail = c->tail_valid && v.H == c->H;
     const int rpw = gram_rows_per_wave(v.Np, c->n_cu);
     const int gblocks = (int)((v.Np + 4 * rpw - 1) / (4 * rpw));
-    const int stat_blocks2 = c->n_cov > 0 ? (v.statBlocks + 1) / 2 : 0;
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL(phase1_open_kernel<KT_>, dim3(gblocks + stat_blocks2), dim3(256), 2 * hs_bytes, c->stream, v.H, c->gramPart,
-                                           (int)v.Np, rpw, gblocks, v.Y, c->B[c->bcur], c->meta, c->statPart, v.N, v.Np, (float)c->eps, c->nstat,
-                                           max_k, max_ct, v.statBlocks));
-    HIPCHK(c, hipGetLastError());
+    if (!from_tail) {
+        const int stat_blocks2 = c->n_cov > 0 ? (v.statBlocks + 1) / 2 : 0;
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(phase1_open_kernel<KT_>, dim3(gblocks + stat_blocks2), dim3(256), 2 * hs_bytes, c->stream, v.H, c->gramPart,
+                                               (int)v.Np, rpw, gblocks, v.Y, c->B[c->bcur], c->meta, c->statPart, v.N, v.Np, (float)c->eps, c->nstat,
+                                               max_k, max_ct, v.statBlocks));
+        HIPCHK(c, hipGetLastError());
+    }
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
     if ((rc = launch_sweep(c, v.gA, v.Xng, v.H, c->piecesA, 0))) return rc;
     if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
     Phase1Reduce a{};
     const int64_t n4 = (int64_t)c->Gp * KP / 4;
     a.nb_pieces = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu * 8, (n4 + 255) / 256));
-    a.nb_many = (KP * KP + 63) / 64;
+    a.nb_many = (KP * KP + 15) / 16;
     a.nb_stats = c->nstat + 1;
     a.pieces = c->piecesA; a.xht = c->red; a.rows = (int)c->Gp;
-    a.gram_part = c->gramPart; a.hht = c->red + c->red_hht; a.n_hht = KP * KP; a.n_slab = gblocks;
-    a.stat_part = c->statPart; a.kind = c->kind; a.stats = c->red + c->red_stats; a.stat_blocks = v.statBlocks; a.nstat = c->nstat; a.xnorm2 = c->xnorm2;
+    a.gram_part = from_tail ? c->gramPartH : c->gramPart; a.hht = c->red + c->red_hht; a.n_hht = KP * KP; a.n_slab = from_tail ? c->tail_blocks : gblocks;
+    a.stat_part = from_tail ? c->statPartH : c->statPart; a.kind = c->kind; a.stats = c->red + c->red_stats; a.stat_blocks = v.statBlocks; a.nstat = c->nstat; a.xnorm2 = c->xnorm2;
     hipLaunchKernelGGL(phase1_reduce_kernel, dim3(a.nb_pieces + a.nb_many + a.nb_stats), dim3(256), 0, c->stream, a, KP, v.gA);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -819,7 +866,8 @@ static int grow_losses(alpine_ctx* c)
     return 0;
 }
 
-static int launch_w_update(alpine_ctx* c, const float* HHt, bool update, int k_lo, int k_hi, bool block_orth)
+// gram_part != nullptr: the kernel also writes one partial block of W_new^T W_new per 128 genes (MFMA form only)
+static int launch_w_update(alpine_ctx* c, const float* HHt, bool update, int k_lo, int k_hi, bool block_orth, float* gram_part = nullptr)
 {
     const int KP = c->KP;
     const float l2 = (float)((1.0 - c->l1r) * c->alpha), l1 = (float)(c->l1r * c->alpha);
@@ -830,29 +878,48 @@ static int launch_w_update(alpine_ctx* c, const float* HHt, bool update, int k_l
                                                block_orth ? 1 : 0));
     } else {
         // 32 genes per wave: ceil(G/128) blocks; the remaining dotpart entries stay at their initial zero
-        DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_mfma_kernel<KT_>, dim3((c->G + 127) / 128), dim3(256), sizeof(float) * KP * KP, c->stream, c->W, c->red,
+        const size_t bytes = sizeof(float) * (KP * KP + 4 * 32 * (KP + 4));          // M + the waves' row-major tiles
+        DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_mfma_kernel<KT_>, dim3((c->G + 127) / 128), dim3(256), bytes, c->stream, c->W, c->red,
                                                HHt, c->dotpart, c->G, c->K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0, k_lo, k_hi,
-                                               block_orth ? 1 : 0));
+                                               block_orth ? 1 : 0, gram_part));
     }
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
-static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi, int only_cov)
+static void cov_maxima(const alpine_ctx* c, int* max_k, int* max_ct)
+{
+    int mk = 1, mc = 1;
+    for (int i = 0; i < c->n_cov; ++i) { mk = std::max(mk, c->cov_k[i]); mc = std::max(mc, c->cov_lev[i]); }
+    *max_k = mk; *max_ct = std::min(HS_CT, mc);
+}
+
+// with_tail: MU branch on the whole shard -> the kernel also emits the next phase 1's H H^T partial blocks and covariate
+// statistics (HTail in kernels.hpp)
+static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi, int only_cov, bool with_tail = false)
 {
     const int KP = c->KP, K = c->K;
     const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
-    const size_t h_bytes_mfma = sizeof(float) * (KP * KP + ((std::max(1, c->nB) + 3) & ~3) + 4 * 32 * (KP + 4));   // + per-wave transpose scratch
+    size_t h_bytes_mfma = sizeof(float) * (KP * KP + ((std::max(1, c->nB) + 3) & ~3) + 4 * 32 * (KP + 4));   // + per-wave transpose scratch
     if (c->h_update_valu && !c->use_als) {   // reference implementation of the same update on the VALU (A/B and fallback)
         const int hblocks = (int)((v.N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
                                                c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
     } else {
+        HTail tail{};
         const int hblocks = (int)((v.N + 127) / 128);
+        if (with_tail) {
+            int max_k, max_ct;
+            cov_maxima(c, &max_k, &max_ct);
+            tail.gram_part = c->gramPartH; tail.stat_part = c->statPartH;
+            tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
+            h_bytes_mfma += 2 * hstats_group_bytes(max_k, max_ct);
+        }
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
-                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov));
+                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov, tail));
     }
     HIPCHK(c, hipGetLastError());
+    c->tail_valid = with_tail && !c->h_update_valu;
     return 0;
 }
 
@@ -893,10 +960,31 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
     int rc;
     const int KP = c->KP, K = c->K;
     const float* HHt = c->red + c->red_hht;
-    // MU: this launch also updates W; block-coordinate: dot partials only (the group loop below updates W)
-    if ((rc = launch_w_update(c, HHt, update && !c->use_als, 0, K, false))) return rc;
+    const bool mu = update && !c->use_als;
+    const bool fused_w = mu && c->fused_w && !c->h_update_valu;
+    // MU: this launch also updates W (and, fused, emits the partial blocks of W_new^T W_new); block-coordinate: dot partials
+    // only (the group loop below updates W)
+    if ((rc = launch_w_update(c, HHt, mu, 0, K, false, fused_w ? c->gramPart : nullptr))) return rc;
     if (finalize && c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
     double* loss_row = c->loss_dev + c->loss_rows * (c->n_cov + 2);
+    if (fused_w) {
+        // ... then ONE launch: partial blocks -> the other W^T W buffer || pending loss row (current buffer) || B updates
+        Phase2Tail a{};
+        a.nb_slabs = (KP * KP + 15) / 16; a.n_slab = (c->G + 127) / 128;
+        a.do_loss = finalize ? 1 : 0; a.do_b = c->n_cov > 0 ? 1 : 0;
+        float* other = c->WtW == c->WtWbuf[0] ? c->WtWbuf[1] : c->WtWbuf[0];
+        a.gram_part = c->gramPart; a.WtW_new = other;
+        a.dotpart = c->dotpart; a.ndot = c->ndot; a.WtW_old = c->WtW; a.HHt = HHt; a.stats = c->red + c->red_stats; a.nstat = c->nstat;
+        a.lam64 = c->lam_dev; a.row = loss_row;
+        a.Bold = c->B[c->bcur]; a.Bnew = c->B[c->bcur ^ 1]; a.eps = (float)c->eps;
+        hipLaunchKernelGGL(phase2_tail_kernel, dim3(a.nb_slabs + 2), dim3(256), 0, c->stream, a, c->meta, KP);
+        HIPCHK(c, hipGetLastError());
+        c->WtW = other;
+        if (finalize) c->loss_rows++;
+        if (c->n_cov > 0) c->bcur ^= 1;
+        if ((rc = launch_sweep_wtx(c, v))) return rc;
+        return launch_h_update(c, v, 0, K, -1, v.H == c->H && !c->no_tail);
+    }
     if (update && !c->use_als && !c->unfused_mid) {
         // MU branch: gram(W_new) partials, the pending loss row and the B updates share one launch (phase2_mid_kernel)
         const int rpw = gram_rows_per_wave(c->Gp, c->n_cu);
@@ -915,7 +1003,7 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
         hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, c->WtW, n, a.gram_blocks);
         HIPCHK(c, hipGetLastError());
         if ((rc = launch_sweep_wtx(c, v))) return rc;
-        return launch_h_update(c, v, 0, K, -1);
+        return launch_h_update(c, v, 0, K, -1, v.H == c->H && !c->no_tail);
     }
     if (finalize) {
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, HHt,
@@ -1238,6 +1326,7 @@ extern "C" int alpine_transform(alpine_ctx* c, int n_iter)
                                            c->piecesB, c->geomB, c->WtW, c->N, c->K, (float)c->eps, n_iter));
     HIPCHK(c, hipGetLastError());
     c->pending_loss = false;
+    c->tail_valid = false;
     return 0;
 }
 
@@ -1296,6 +1385,7 @@ extern "C" int alpine_scale(alpine_ctx* c)
     if (c->n_cov > 0) hipLaunchKernelGGL(scale_b_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->meta, c->scale);
     HIPCHK(c, hipGetLastError());
     c->pending_loss = false;      // W^TW / reduce terms no longer describe these factors
+    c->tail_valid = false;
     return 0;
 }
 

@@ -300,7 +300,16 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
     }
 }
 
-// out[f][k] = sum over the pieces of f's tile (ascending workgroup, float64 accumulation), f < rows
+// Offset of the piece that workgroup w wrote for tile ft, for w_lo < w <= w_hi (w_lo = first workgroup that touches ft):
+// such a workgroup's span STARTS inside ft, so ft is its piece 0 -- no division needed.
+__device__ __forceinline__ int64_t sg_piece_offset_inner(const SweepGeom& g, int w, int KP)
+{
+    return (int64_t)w * g.maxp * g.bf * KP;
+}
+
+// out[f][k] = sum over the pieces of f's tile (ascending workgroup, float64 accumulation), f < rows.
+// The piece loop is latency-bound when written one load per trip (a tile has ~13 pieces on the fixed stream-K grid,
+// whatever the shard size): loads are issued four pieces at a time, the adds stay in ascending order.
 __device__ __forceinline__ void reduce_pieces_block(const float* __restrict__ pieces, float* __restrict__ out, int rows, int KP, const SweepGeom& g,
                                                     int block, int nblocks)
 {
@@ -311,9 +320,19 @@ __device__ __forceinline__ void reduce_pieces_block(const float* __restrict__ pi
         const int ft = f / g.bf, fl = f % g.bf;
         int w_lo, w_hi;
         sg_tile_pieces(g, ft, w_lo, w_hi);
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int w = w_lo; w <= w_hi; ++w) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl * KP + 4 * k4);
+        const int64_t in_piece = (int64_t)fl * KP + 4 * k4;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w_lo, ft, KP) + in_piece);
+        double a0 = v0[0], a1 = v0[1], a2 = v0[2], a3 = v0[3];
+        int w = w_lo + 1;
+        for (; w + 3 <= w_hi; w += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset_inner(g, w + u, KP) + in_piece);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; a2 += v[u][2]; a3 += v[u][3]; }
+        }
+        for (; w <= w_hi; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset_inner(g, w, KP) + in_piece);
             a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
         }
         f32x4 o = {(float)a0, (float)a1, (float)a2, (float)a3};
@@ -448,8 +467,11 @@ __host__ __device__ inline size_t hstats_group_bytes(int max_k, int max_ct)
 // One group = 128 threads = 128 cells; a block may hold several groups (`group` = index inside the block, `gblock` = the
 // group's global index = row of `part`): every group has its own slice of the dynamic LDS, barriers are block-wide (all
 // groups run the same trip counts).
-__device__ __forceinline__ void hstats_group(const float* __restrict__ H, const float* __restrict__ Y, const float* __restrict__ B,
-                                             const CovMeta& meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat,
+// hrow(k) = H[this thread's cell][k]: a row of the cell-major H in global memory (stand-alone kernel) or of the updated tile
+// that the H update still holds in LDS (fused tail).
+template <typename HRow>
+__device__ __forceinline__ void hstats_group(HRow hrow, const float* __restrict__ Y, const float* __restrict__ B,
+                                             const CovMeta& meta, float* __restrict__ part, int N, int64_t Np, float eps, int nstat,
                                              int max_k, int max_ct, unsigned char* __restrict__ smem_base, int group, int64_t gblock)
 {
     // dynamic LDS sized for THIS model (max_k = largest k_i, max_ct = min(HS_CT, largest C_i)): a few KB instead of the
@@ -469,7 +491,7 @@ __device__ __forceinline__ void hstats_group(const float* __restrict__ H, const 
         const float lam = meta.lam[i];
         float* so = out + meta.soff[i];
         __syncthreads();
-        for (int k = 0; k < ki; ++k) hbuf[k][t] = valid ? H[n * KP + off + k] : 0.f;
+        for (int k = 0; k < ki; ++k) hbuf[k][t] = valid ? hrow(off + k) : 0.f;
         double lacc = 0.0;
         for (int c0 = 0; c0 < Ci; c0 += HS_CT) {
             const int ct = min(HS_CT, Ci - c0);
@@ -526,7 +548,8 @@ void hstats_kernel(const float* __restrict__ H, const float* __restrict__ Y, con
                    CovMeta meta, float* __restrict__ part, int N, int64_t Np, int KP, float eps, int nstat, int max_k, int max_ct)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_smem[];
-    hstats_group(H, Y, B, meta, part, N, Np, KP, eps, nstat, max_k, max_ct, hs_smem, 0, blockIdx.x);
+    const float* hr = H + ((int64_t)blockIdx.x * HS_CELLS + (threadIdx.x & (HS_CELLS - 1))) * KP;
+    hstats_group([hr](int k) { return hr[k]; }, Y, B, meta, part, N, Np, eps, nstat, max_k, max_ct, hs_smem, 0, blockIdx.x);
 }
 
 // The two small kernels that open phase 1 (both read only the old H) in ONE launch: blocks [0, gram_blocks) compute the
@@ -546,7 +569,8 @@ void phase1_open_kernel(const float* __restrict__ H, float* __restrict__ gram_pa
     // a block whose second group lies past the last cell still walks the same barriers: it works on the last valid
     // group's cells again and writes the same values to the same row
     if (gblock >= stat_groups) gblock = stat_groups - 1;
-    hstats_group(H, Y, B, meta, stat_part, N, Np, KP, eps, nstat, max_k, max_ct, hs_smem, group, gblock);
+    const float* hr = H + (gblock * HS_CELLS + (threadIdx.x & (HS_CELLS - 1))) * KP;
+    hstats_group([hr](int k) { return hr[k]; }, Y, B, meta, stat_part, N, Np, eps, nstat, max_k, max_ct, hs_smem, group, gblock);
 }
 
 // stats[j] = sum over blocks of part[blk][j] in float64; kind[j]: 0 plain, 1 = hi word of a (hi,lo) pair
@@ -592,16 +616,44 @@ void reduce_stats_kernel(const float* __restrict__ part, const int* __restrict__
     reduce_stats_block(part, kind, stats, nblk, nstat, xnorm2, blockIdx.x);
 }
 
-// out[j] = sum_s in[s][j] with 256 threads: 64 outputs x 4 slab groups, groups combined in group order (float64)
-__device__ __forceinline__ void reduce_many_block256(const float* __restrict__ in, float* __restrict__ out, int n, int nslab, int block)
+// out[j] = sum_s in[s][j] for MANY slabs (one per 128-cell block of the fused H update: hundreds to thousands): a block owns
+// 16 consecutive outputs (4 lanes x float4) and spreads the slabs over 64 slab lanes, 8 loads in flight per thread; the
+// slab lanes are combined by a fixed tree in float64 -> the sum order depends only on (n, nslab): reproducible.
+__device__ __forceinline__ void reduce_slabs_block(const float* __restrict__ in, float* __restrict__ out, int n, int nslab, int block)
 {
-    __shared__ double red4[4][64];
-    const int j = block * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
-    double a = 0.0;
-    if (j < n) for (int sl = sg; sl < nslab; sl += 4) a += (double)in[(int64_t)sl * n + j];
-    red4[sg][threadIdx.x & 63] = a;
+    __shared__ double red[64][17];                       // [slab lane][16 outputs], padded
+    const int q = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int j0 = block * 16 + 4 * q;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (j0 < n) {
+        const float* p = in + j0;
+        int sidx = sl;
+        for (; sidx + 7 * 64 < nslab; sidx += 8 * 64) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(sidx + 64 * u) * n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[0] += v[u][0]; a[1] += v[u][1]; a[2] += v[u][2]; a[3] += v[u][3]; }
+        }
+        for (; sidx < nslab; sidx += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)sidx * n);
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[sl][4 * q + e] = a[e];
     __syncthreads();
-    if (sg == 0 && j < n) out[j] = (float)(red4[0][threadIdx.x] + red4[1][threadIdx.x] + red4[2][threadIdx.x] + red4[3][threadIdx.x]);
+    for (int half = 32; half > 0; half >>= 1) {
+        if (sl < half) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[sl][4 * q + e] += red[sl + half][4 * q + e];
+        }
+        __syncthreads();
+    }
+    if (sl == 0 && j0 < n) {
+        f32x4 o = {(float)red[0][4 * q], (float)red[0][4 * q + 1], (float)red[0][4 * q + 2], (float)red[0][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(out + j0) = o;
+    }
 }
 
 // The three reductions that close phase 1 in ONE launch (they are independent of each other): the pieces of the XH^T
@@ -619,7 +671,7 @@ void phase1_reduce_kernel(Phase1Reduce a, int KP, SweepGeom g)
     int b = blockIdx.x;
     if (b < a.nb_pieces) { reduce_pieces_block(a.pieces, a.xht, a.rows, KP, g, b, a.nb_pieces); return; }
     b -= a.nb_pieces;
-    if (b < a.nb_many) { reduce_many_block256(a.gram_part, a.hht, a.n_hht, a.n_slab, b); return; }
+    if (b < a.nb_many) { reduce_slabs_block(a.gram_part, a.hht, a.n_hht, a.n_slab, b); return; }
     b -= a.nb_many;
     reduce_stats_block(a.stat_part, a.kind, a.stats, a.stat_blocks, a.nstat, a.xnorm2, b);
 }
@@ -911,10 +963,29 @@ __device__ __forceinline__ void sg_sum_pieces_rows(const float* __restrict__ pie
 {
     constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4, NI = (32 * Q4) / 64;
     f32x4 acc[NI];
+    {
+        const float* base = pieces + sg_piece_offset(g, w_lo, ft, KP) + (int64_t)fl0 * KP;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int w = w_lo; w <= w_hi; ++w) {
-        const float* base = pieces + sg_piece_offset(g, w, ft, KP) + (int64_t)fl0 * KP;
+        for (int i = 0; i < NI; ++i) acc[i] = *reinterpret_cast<const f32x4*>(base + 4 * (64 * i + lane));
+    }
+    // two pieces (2 * NI 1-KiB loads per wave) in flight per trip: on the fixed stream-K grid a tile has ~10 pieces at
+    // every shard size and a trip per piece costs one full memory latency; the adds stay in ascending workgroup order
+    int w = w_lo + 1;
+    for (; w + 1 <= w_hi; w += 2) {
+        const float* b0 = pieces + sg_piece_offset_inner(g, w, KP) + (int64_t)fl0 * KP;
+        const float* b1 = pieces + sg_piece_offset_inner(g, w + 1, KP) + (int64_t)fl0 * KP;
+        f32x4 v0[NI], v1[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v0[i] = *reinterpret_cast<const f32x4*>(b0 + 4 * (64 * i + lane));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v1[i] = *reinterpret_cast<const f32x4*>(b1 + 4 * (64 * i + lane));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += v0[i];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += v1[i];
+    }
+    if (w <= w_hi) {
+        const float* base = pieces + sg_piece_offset_inner(g, w, KP) + (int64_t)fl0 * KP;
         f32x4 v[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const f32x4*>(base + 4 * (64 * i + lane));
@@ -940,16 +1011,61 @@ __device__ __forceinline__ void sg_sum_pieces_rows(const float* __restrict__ pie
 //   H rows ARE its B operands, and den lands element-for-element on the same registers' k.  No LDS round trip for H.
 // Guided terms (main.py:636-650) use the same registers: per covariate/class the lane forms its half of
 // (B_i H_i)[c'][cell] over the k it owns and adds the partner half (lane ^ 32).
+//
+// Fused tail (MU branch on the whole shard): the updated H is the OLD H of the next iteration's phase 1, and every wave
+// still holds its 32 x KP tile of it in LDS (the row-major image behind the global store).  So the block also emits what
+// phase1_open_kernel would compute from a re-read of H: its partial block of H H^T (gram_part[block], the block's 128 cells
+// as the contraction axis, each wave owning output tiles t = wave, wave + 4, ... of the KT x KT grid) and the covariate
+// statistics of its 128-cell group (stat_part[block], same arithmetic as hstats_kernel).  The next phase 1 then starts
+// directly with the XH^T sweep.  (One group per block, straight-line code: a loop over several groups makes the compiler
+// keep the loop-invariant LDS operands in registers and spill.)
+// A^T A over the 128 rows that the four waves of a block hold as row-major 32 x (KP + 4) tiles in LDS (trall), written to
+// gout[k][k'] (KP x KP): v_mfma_f32_32x32x2_f32 with A[i = k][kk = row], B[kk = row][j = k'], two rows per step; wave w owns
+// the output tiles t = w, w + 4, ... of the KT x KT grid, so no cross-wave reduction is needed.  Used by the tails of
+// the H update (H H^T of the updated H) and of the W update (W^T W of the updated W).
+template <int KT>
+__device__ __forceinline__ void gram_of_lds_tiles(const float* __restrict__ trall, int wave, int lane, float* __restrict__ gout)
+{
+    constexpr int KP = 32 * KT, LD = KP + 4, TRSZ = 32 * LD, NTW = (KT * KT + 3) / 4;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int t = wave + 4 * u;                                        // wave-uniform
+        if (KT * KT % 4 != 0 && t >= KT * KT) break;
+        const int ta = t / KT, tb = t % KT;
+        f32x16 gacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gacc[e] = 0.f;
+        const float* pa = trall + h * LD + 32 * ta + c;                    // row 2p + h of tile (2p + h) >> 5
+        const float* pb = trall + h * LD + 32 * tb + c;
+#pragma unroll 8
+        for (int p2 = 0; p2 < 64; ++p2) {
+            const int o = (p2 >> 4) * TRSZ + ((2 * p2) & 31) * LD;
+            gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[o], pb[o], gacc, 0, 0, 0);
+        }
+        // D layout: row (k) = 32 ta + (e & 3) + 8 (e >> 2) + 4 h, column (k') = 32 tb + c
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            gout[(32 * ta + (e & 3) + 8 * (e >> 2) + 4 * h) * KP + 32 * tb + c] = gacc[e];
+    }
+}
+
+struct HTail {
+    float* gram_part;       // [gridDim.x][KP*KP], nullptr = no tail
+    float* stat_part;       // [groups][nstat]
+    int nstat, max_k, max_ct;
+};
+
 template <int KT>
 __global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
 void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
                           const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
-                          CovMeta meta, int N, int64_t Np, int K, float eps, int nB, int k_lo, int k_hi, int only_cov)
+                          CovMeta meta, int N, int64_t Np, int K, float eps, int nB, int k_lo, int k_hi, int only_cov, HTail tail)
 {
     // MU branch: k_lo = 0, k_hi = K, only_cov = -1.  Block-coordinate branch (main.py:564-588): only the rows
     // [k_lo, k_hi) of one component group are updated; guided terms only for that group's covariate (only_cov),
     // none for the unguided group (only_cov = n_cov).
-    constexpr int KP = 32 * KT;
+    constexpr int KP = 32 * KT, LD = KP + 4, TRSZ = 32 * LD;
     constexpr int GT = KT < 2 ? KT : 2;            // k tiles that can hold guided columns (sum k_i <= 64)
     extern __shared__ float smem[];
     float* M2l = smem;                             // [k'][k] = 2 * WtW
@@ -957,95 +1073,118 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    float* tr = smem + KP * KP + ((nB + 3) & ~3) + wave * (32 * (KP + 4));     // this wave's 32 x (KP + 4) transpose scratch
+    float* trall = smem + KP * KP + ((nB + 3) & ~3);                 // 4 x [32][KP + 4]: the waves' tiles of one 128-cell group
+    float* tr = trall + wave * TRSZ;
+    unsigned char* hs_smem = reinterpret_cast<unsigned char*>(trall + 4 * TRSZ);   // tail only: 2 x hstats_group_bytes
+    const bool with_tail = tail.gram_part != nullptr;
     for (int idx = tid; idx < KP * KP; idx += 256) M2l[idx] = 2.f * WtW[idx];
     for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];
     __syncthreads();
 
-    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-    if (n0 >= N) return;
-    const int64_t n = n0 + c;
-    const bool valid = n < N;
-    const int ft = (int)(n0 / g.bf), fl0 = (int)(n0 % g.bf);
-    int w_lo, w_hi;
-    sg_tile_pieces(g, ft, w_lo, w_hi);
+    {
+        const int64_t grp = blockIdx.x;                                        // 128-cell group
+        const int64_t n0 = (grp * 4 + wave) * 32;
+        if (n0 < N) {                                                          // wave-uniform
+            const int64_t n = n0 + c;
+            const bool valid = n < N;
+            const int ft = (int)(n0 / g.bf), fl0 = (int)(n0 % g.bf);
+            int w_lo, w_hi;
+            sg_tile_pieces(g, ft, w_lo, w_hi);
 
-    // whole-row global accesses, C/D layout in registers (rows n0 .. n0+31 exist: H and the pieces are padded to 128 rows)
-    f32x4 hreg[KT][4], xreg[KT][4];
-    sg_sum_pieces_rows<KT>(pieces, g, ft, fl0, w_lo, w_hi, tr, lane, xreg);
-    tile_load_cd<KT>(H + n0 * KP, tr, lane, hreg);
+            // whole-row global accesses, C/D layout in registers (rows n0 .. n0+31 exist: H and the pieces are padded to 128 rows)
+            f32x4 hreg[KT][4], xreg[KT][4];
+            sg_sum_pieces_rows<KT>(pieces, g, ft, fl0, w_lo, w_hi, tr, lane, xreg);
+            tile_load_cd<KT>(H + n0 * KP, tr, lane, hreg);
 
-    f32x16 acc[KT];
+            f32x16 acc[KT];
 #pragma unroll
-    for (int mo = 0; mo < KT; ++mo)
+            for (int mo = 0; mo < KT; ++mo)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mo][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[mo][e] = 0.f;
 #pragma unroll
-    for (int m = 0; m < KT; ++m)
+            for (int m = 0; m < KT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float* mrow = M2l + (32 * m + 8 * q + 4 * h + e) * KP + c;
+                    for (int e = 0; e < 4; ++e) {
+                        const float* mrow = M2l + (32 * m + 8 * q + 4 * h + e) * KP + c;
 #pragma unroll
-                for (int mo = 0; mo < KT; ++mo)
-                    acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], hreg[m][q][e], acc[mo], 0, 0, 0);
+                        for (int mo = 0; mo < KT; ++mo)
+                            acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], hreg[m][q][e], acc[mo], 0, 0, 0);
+                    }
+
+            // numerator = 2 W^TX (+ guided), denominator = (2 W^TW) H (+ guided): accumulated IN PLACE in xreg / acc so that the
+            // kernel's live state stays at three tiles (H, numerator, denominator) -> 2 waves per SIMD
+#pragma unroll
+            for (int m = 0; m < KT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xreg[m][q] = 2.f * xreg[m][q];
+            for (int i = 0; i < meta.n_cov; ++i) {
+                if (only_cov >= 0 && i != only_cov) continue;
+                const int off = meta.off[i], ki = meta.k[i], Ci = meta.lev[i], bo = meta.boff[i];
+                const float lam = (meta.loss_type == 0) ? meta.lam[i] : meta.lam2[i];
+                for (int cl = 0; cl < Ci; ++cl) {
+                    const float* brow = Bl + bo + cl * ki - off;            // brow[k] = B_i[cl][k - off]
+                    float part = 0.f;
+#pragma unroll
+                    for (int m = 0; m < GT; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int k = 32 * m + 8 * q + 4 * h + e;
+                                const float coef = (k >= off && k < off + ki) ? brow[k] : 0.f;
+                                part = fmaf(coef, hreg[m][q][e], part);
+                            }
+                    const float bh = part + __shfl_xor(part, 32, 64);
+                    const float y = valid ? Y[(int64_t)(meta.yoff[i] + cl) * Np + n] : 0.f;
+                    const float z = (meta.loss_type == 0) ? y / fmaxf(bh, eps) : y;
+#pragma unroll
+                    for (int m = 0; m < GT; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int k = 32 * m + 8 * q + 4 * h + e;
+                                const float lb = (k >= off && k < off + ki) ? lam * brow[k] : 0.f;
+                                xreg[m][q][e] = fmaf(lb, z, xreg[m][q][e]);
+                                acc[m][4 * q + e] = (meta.loss_type == 0) ? acc[m][4 * q + e] + lb : fmaf(lb, bh, acc[m][4 * q + e]);
+                            }
+                }
             }
 
-    // numerator = 2 W^TX (+ guided), denominator = (2 W^TW) H (+ guided): accumulated IN PLACE in xreg / acc so that the
-    // kernel's live state stays at three tiles (H, numerator, denominator) -> 2 waves per SIMD
 #pragma unroll
-    for (int m = 0; m < KT; ++m)
+            for (int m = 0; m < KT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xreg[m][q] = 2.f * xreg[m][q];
-    for (int i = 0; i < meta.n_cov; ++i) {
-        if (only_cov >= 0 && i != only_cov) continue;
-        const int off = meta.off[i], ki = meta.k[i], Ci = meta.lev[i], bo = meta.boff[i];
-        const float lam = (meta.loss_type == 0) ? meta.lam[i] : meta.lam2[i];
-        for (int cl = 0; cl < Ci; ++cl) {
-            const float* brow = Bl + bo + cl * ki - off;            // brow[k] = B_i[cl][k - off]
-            float part = 0.f;
-#pragma unroll
-            for (int m = 0; m < GT; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) {
+                    const int k4 = 32 * m + 8 * q + 4 * h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int k = 32 * m + 8 * q + 4 * h + e;
-                        const float coef = (k >= off && k < off + ki) ? brow[k] : 0.f;
-                        part = fmaf(coef, hreg[m][q][e], part);
+                        const float v = hreg[m][q][e] * (xreg[m][q][e] / fmaxf(acc[m][4 * q + e], eps));
+                        const int k = k4 + e;
+                        if (k >= k_lo && k < k_hi) hreg[m][q][e] = v;           // outside the range (and pads, which are 0): unchanged
+                        if (with_tail && !valid) hreg[m][q][e] = 0.f;           // rows past the last cell must not enter the sums of the tail
                     }
-            const float bh = part + __shfl_xor(part, 32, 64);
-            const float y = valid ? Y[(int64_t)(meta.yoff[i] + cl) * Np + n] : 0.f;
-            const float z = (meta.loss_type == 0) ? y / fmaxf(bh, eps) : y;
-#pragma unroll
-            for (int m = 0; m < GT; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 32 * m + 8 * q + 4 * h + e;
-                        const float lb = (k >= off && k < off + ki) ? lam * brow[k] : 0.f;
-                        xreg[m][q][e] = fmaf(lb, z, xreg[m][q][e]);
-                        acc[m][4 * q + e] = (meta.loss_type == 0) ? acc[m][4 * q + e] + lb : fmaf(lb, bh, acc[m][4 * q + e]);
-                    }
+                }
+            (void)K;
+            // leaves the updated tile row-major in tr (the tail reads it there)
+            tile_store_cd<KT>(H + n0 * KP, tr, lane, hreg, (int)min((int64_t)32, (int64_t)N - n0));
+        } else if (with_tail) {
+            for (int idx = lane; idx < TRSZ / 4; idx += 64) reinterpret_cast<f32x4*>(tr)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!with_tail) return;                                                // kernel-uniform
+
+        __syncthreads();                                                       // the four tiles of this group are in LDS
+        gram_of_lds_tiles<KT>(trall, wave, lane, tail.gram_part + (int64_t)blockIdx.x * KP * KP);      // H H^T over the block's 128 cells
+        if (meta.n_cov > 0) {
+            // covariate statistics of this 128-cell group; threads 128..255 walk the same barriers on the same cells with
+            // their own scratch slice and write the same values (as phase1_open_kernel's odd last group does)
+            const int t7 = tid & (HS_CELLS - 1);
+            const float* hr = trall + (t7 >> 5) * TRSZ + (t7 & 31) * LD;
+            hstats_group([hr](int k) { return hr[k]; }, Y, B, meta, tail.stat_part, N, Np, eps, tail.nstat, tail.max_k, tail.max_ct,
+                         hs_smem, tid >> 7, grp);
         }
     }
-
-#pragma unroll
-    for (int m = 0; m < KT; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k4 = 32 * m + 8 * q + 4 * h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = hreg[m][q][e] * (xreg[m][q][e] / fmaxf(acc[m][4 * q + e], eps));
-                const int k = k4 + e;
-                if (k >= k_lo && k < k_hi) hreg[m][q][e] = v;               // outside the range (and pads, which are 0): unchanged
-            }
-        }
-    (void)K;
-    tile_store_cd<KT>(H + n0 * KP, tr, lane, hreg, (int)min((int64_t)32, (int64_t)N - n0));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1057,13 +1196,17 @@ template <int KT>
 __global__ __launch_bounds__(256)
 void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, const float* __restrict__ HHt,
                           double* __restrict__ dotpart, int G, int K, float orth, float l2, float l1, float eps,
-                          int do_update, int k_lo, int k_hi, int block_orth)
+                          int do_update, int k_lo, int k_hi, int block_orth, float* __restrict__ gram_part)
 {
-    constexpr int KP = 32 * KT;
+    // gram_part != nullptr (MU branch): the block also writes its partial block of W_new^T W_new (the 128 updated rows are
+    // still in LDS behind the global store) -> no separate pass over W for W^T W.
+    constexpr int KP = 32 * KT, LD = KP + 4, TRSZ = 32 * LD;
     extern __shared__ float Ml[];
+    float* trall = Ml + KP * KP;                    // 4 x [32][KP + 4] row-major tiles of the updated rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
+    float* tr = trall + wave * TRSZ;
     if (do_update) {
         for (int idx = tid; idx < KP * KP; idx += 256) {
             const int kp = idx / KP, k = idx % KP;
@@ -1077,20 +1220,21 @@ void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, 
         __syncthreads();
     }
     const int gw = blockIdx.x * 4 + wave;
-    const int64_t g = (int64_t)gw * 32 + c;
+    const int64_t g0 = (int64_t)gw * 32;
+    const int64_t g = g0 + c;
     const bool valid = g < G;
+    // W and XH^T are padded to 128 rows: the wave's 32 rows exist; whole-row loads, C/D layout in registers
     f32x4 wreg[KT][4], xreg[KT][4];
+    tile_load_cd<KT>(W + g0 * KP, tr, lane, wreg);
+    tile_load_cd<KT>(XHt + g0 * KP, tr, lane, xreg);
     double dacc = 0.0;
 #pragma unroll
     for (int m = 0; m < KT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k4 = 32 * m + 8 * q + 4 * h;
-            wreg[m][q] = valid ? *reinterpret_cast<const f32x4*>(W + g * KP + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            xreg[m][q] = valid ? *reinterpret_cast<const f32x4*>(XHt + g * KP + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) dacc += (double)xreg[m][q][e] * (double)wreg[m][q][e];
-        }
+    if (!valid) dacc = 0.0;
     dacc = wave_sum_f64(dacc);
     if (lane == 0) dotpart[gw] = dacc;
     if (!do_update) return;
@@ -1111,23 +1255,25 @@ void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, 
                 for (int mo = 0; mo < KT; ++mo)
                     acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], wreg[m][q][e], acc[mo], 0, 0, 0);
             }
-    if (!valid) return;
 #pragma unroll
     for (int m = 0; m < KT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k4 = 32 * m + 8 * q + 4 * h;
-            if (k4 >= k_hi || k4 + 4 <= k_lo) continue;
-            f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = k4 + e;
                 const float d = fmaxf(acc[m][4 * q + e] + l1, eps);
                 const float v = wreg[m][q][e] * ((2.f * xreg[m][q][e]) / d);
-                o[e] = (k >= k_lo && k < k_hi) ? v : wreg[m][q][e];
+                if (k >= k_lo && k < k_hi) wreg[m][q][e] = v;
+                if (!valid) wreg[m][q][e] = 0.f;                                      // pad rows stay exactly zero
             }
-            *reinterpret_cast<f32x4*>(W + g * KP + k4) = o;
         }
+    // full-line stores through the wave's LDS tile, which stays behind for the W^T W partial
+    tile_store_cd<KT>(W + g0 * KP, tr, lane, wreg, (int)min((int64_t)32, (int64_t)G - g0));
+    if (gram_part == nullptr) return;                                                // kernel-uniform
+    __syncthreads();
+    gram_of_lds_tiles<KT>(trall, wave, lane, gram_part + (int64_t)blockIdx.x * KP * KP);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1287,6 +1433,28 @@ struct Phase2Mid {
     const double* dotpart; int ndot; const float* WtW; const float* HHt; const float* stats; int nstat; const double* lam64; double* row;
     const float* Bold; float* Bnew; float eps;
 };
+
+// After the fused W update (w_update_mfma_kernel with gram_part): ONE launch for the reduction of its W^T W partial blocks
+// into the OTHER W^T W buffer (blocks [0, nb_slabs)), the pending loss row (reads the CURRENT buffer = W^T W of the W that
+// produced the reduce block) and the B updates.  The host then swaps the two W^T W buffers.
+struct Phase2Tail {
+    int nb_slabs, n_slab, do_loss, do_b;
+    const float* gram_part; float* WtW_new;
+    const double* dotpart; int ndot; const float* WtW_old; const float* HHt; const float* stats; int nstat; const double* lam64; double* row;
+    const float* Bold; float* Bnew; float eps;
+};
+
+__global__ __launch_bounds__(256)
+void phase2_tail_kernel(Phase2Tail a, CovMeta meta, int KP)
+{
+    const int b = blockIdx.x;
+    if (b < a.nb_slabs) { reduce_slabs_block(a.gram_part, a.WtW_new, KP * KP, a.n_slab, b); return; }
+    if (b == a.nb_slabs) {
+        if (a.do_loss) loss_finalize_block(a.dotpart, a.ndot, a.WtW_old, a.HHt, a.stats, meta, a.nstat, KP, a.lam64, a.row);
+        return;
+    }
+    if (a.do_b) b_update_block(a.Bold, a.Bnew, a.stats, a.HHt, meta, KP, a.eps);
+}
 
 template <int KT>
 __global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))

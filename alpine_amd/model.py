@@ -68,6 +68,7 @@ class ALPINE:
         shard_cells: Union[bool, str] = False,
         x_dtype: str = "x3",
         shard_comm: str = "auto",
+        keep_resident: bool = True,
     ):
         self.n_components = n_components
         self.n_covariate_components = n_covariate_components
@@ -97,6 +98,13 @@ class ALPINE:
         if shard_comm not in ("auto", "native", "torch"):
             raise ValueError("shard_comm must be 'auto', 'native' or 'torch'")
         self.shard_comm = shard_comm
+        # extension: after a single-device fit the engine (with both copies of X in HBM) stays alive, so that a following
+        # compute_loss(adata) / transform(adata) ON THE SAME adata.X does not upload X again (at 20k x 200k one upload costs
+        # as much as 50-100 iterations).  release() frees it; False frees it at the end of fit() like the reference does.
+        if not isinstance(keep_resident, bool):
+            raise TypeError("keep_resident must be a boolean.")
+        self.keep_resident = keep_resident
+        self._resident = None
         # extension: storage / matrix-pipe mode of the two sweeps (the reference has float32 only).
         #   "x3" (default)  X float32 in HBM; every product is formed from the exact bf16 planes of both factors on the
         #                   bf16 matrix pipe (six plane products, float32 accumulate): float32-grade results for ANY X at
@@ -147,15 +155,25 @@ class ALPINE:
         self.batch_size = batch_size if batch_size is not None else n_global
         self._check_supported(n_global)
 
-        if max_iter is None:
-            # main.py:116-129: 200-iteration warm-up, Kneedle elbow on log10(recon loss)
-            warm = self._run_native(adata.X, Y, 200, scale=False)
-            self.max_iter = self._compute_best_iter(warm["loss_history"]["reconstruction loss"].values)
-            del warm
+        self.release()                                  # a previous fit's resident engine
+        sess = self._open_session(adata.X, Y)           # X is uploaded ONCE, also when the warm-up runs first
+        try:
+            if max_iter is None:
+                # main.py:116-129: 200-iteration warm-up, Kneedle elbow on log10(recon loss); the final run starts again from
+                # the seeded initial factors (the reference re-runs _initialize_matrices, main.py:135) on the SAME resident X
+                warm = self._run_session(sess, 200, scale=False)
+                self.max_iter = self._compute_best_iter(warm["loss_history"]["reconstruction loss"].values)
+                del warm
+            else:
+                self.max_iter = max_iter
+            res = self._run_session(sess, self.max_iter, scale=self.scale_needed)
+        except BaseException:
+            sess["eng"].close()
+            raise
+        if self.keep_resident and not sess["sharded"] and sess["x_dtype"] in ("f32", "x3") and sess["batch_capacity"] == 0:
+            self._resident = dict(eng=sess["eng"], X=adata.X, fingerprint=self._x_fingerprint(adata.X), x_dtype=sess["x_dtype"])
         else:
-            self.max_iter = max_iter
-
-        res = self._run_native(adata.X, Y, self.max_iter, scale=self.scale_needed)
+            sess["eng"].close()
         self.loss_history = res["loss_history"]
         offs = np.cumsum([0] + self.n_all_components)
         X32 = adata.X if adata.X.dtype == np.float32 else adata.X.astype(np.float32)
@@ -196,7 +214,25 @@ class ALPINE:
             return np.unique(np.array([c for p in parts for c in p], dtype=object if cats.dtype == object else None))
         return merge
 
+    # limits of libalpine_hip.so that the reference does not have ("Deviations"): checked here so that the
+    # user gets a Python-side message before any device work, instead of a late native status
+    MAX_TOTAL_COMPONENTS = 128
+    MAX_GUIDED_COMPONENTS = 64
+    MAX_COVARIATES = 16
+
     def _check_supported(self, n_sample: int) -> None:
+        ks = list(self.n_covariate_components)
+        if any(k == 0 for k in ks):
+            raise NotImplementedError("n_covariate_components entries of 0 (a covariate without guided components; the reference "
+                                      "accepts them, main.py:335) are not supported by the MI355X build: drop that covariate instead")
+        if len(ks) > self.MAX_COVARIATES:
+            raise NotImplementedError(f"more than {self.MAX_COVARIATES} covariates are not supported by the MI355X build (got {len(ks)})")
+        if sum(ks) > self.MAX_GUIDED_COMPONENTS:
+            raise NotImplementedError(f"sum(n_covariate_components) = {sum(ks)} > {self.MAX_GUIDED_COMPONENTS}: the guided components "
+                                      "must fit in the first 64 columns of W / H in the MI355X build")
+        if self.total_components > self.MAX_TOTAL_COMPONENTS:
+            raise NotImplementedError(f"n_components + sum(n_covariate_components) = {self.total_components} > "
+                                      f"{self.MAX_TOTAL_COMPONENTS} is not supported by the MI355X build")
         if self.sampling_method not in ("random", "weighted"):
             raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
         if self._uses_batches(n_sample):
@@ -211,8 +247,36 @@ class ALPINE:
         through the gathered mini-batch view."""
         return self.batch_size < n_sample or self.sampling_method == "weighted"
 
-    def _run_native(self, X_cells_genes: np.ndarray, Y: List[np.ndarray], n_iter: int, scale: bool) -> dict:
-        """Upload, initialise exactly like main.py:436-472, run the MU loop on the device(s), read back."""
+    # ------------------------------------------------------------------ resident engine
+    @staticmethod
+    def _x_fingerprint(X: np.ndarray):
+        """Cheap identity of an input matrix: buffer address, shape, strides, dtype and a hash of 64 evenly spaced rows.
+        (An in-place edit of X that misses all sampled rows is not detected -- call release() after mutating X.)"""
+        import hashlib
+        rows = np.unique(np.linspace(0, max(0, X.shape[0] - 1), num=min(64, max(1, X.shape[0]))).astype(np.int64))
+        h = hashlib.blake2b(np.ascontiguousarray(X[rows]).tobytes(), digest_size=16).hexdigest()
+        return (X.ctypes.data, X.shape, X.strides, X.dtype.str, h)
+
+    def _resident_engine_for(self, X: np.ndarray):
+        r = self._resident
+        if r is None or r["X"] is not X or r["fingerprint"] != self._x_fingerprint(X):
+            return None
+        return r["eng"]
+
+    def release(self) -> None:
+        """Free the engine (and the copies of X in HBM) that fit() left resident for compute_loss / transform."""
+        r, self._resident = getattr(self, "_resident", None), None
+        if r is not None:
+            r["eng"].close()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _open_session(self, X_cells_genes: np.ndarray, Y: List[np.ndarray]) -> dict:
+        """Create the engine(s) for this input and upload X and Y once (main.py:445-449); the factors are set per run."""
         N_total, G = X_cells_genes.shape
         dev_index = _parse_device(str(self.device))
         dist, rank, world = self._dist_world()
@@ -240,12 +304,6 @@ class ALPINE:
         n_loc = c1 - c0
         uses_batches = self._uses_batches(N_total)          # N_total is the global cell count from here on
         cov_levels = [y.shape[1] for y in Y]
-        W0, H0, B0 = draw_initial_factors(self.random_state, self.eps, G, N_total, self.n_all_components, cov_levels)
-        # The reference's loop also draws torch.randperm(N) once per iteration from the global generator
-        # (sampling.py:14).  Full batch makes the permutation a numerical no-op, so it is not applied, but a later
-        # unseeded transform() (main.py:687) continues that stream: remember how to advance it lazily.
-        self._rng_post_init = torch.get_rng_state()
-        self._rng_replay = (N_total, n_iter)
 
         x_dtype = self.x_dtype
         if x_dtype == "auto":
@@ -258,8 +316,8 @@ class ALPINE:
                   use_als=self.use_als)
         block, stream = None, None
         if sharded:
-            # The engine and the collective must share ONE explicit stream: the default stream's handle is 0, which
-            # the C ABI reads as "create a private stream", and that would leave the all-reduce unordered with the kernels.
+            # The engine and a torch-carried collective must share ONE explicit stream: the default stream's handle is 0,
+            # which the C ABI reads as "create a private stream", and that would leave the all-reduce unordered with the kernels.
             with torch.cuda.device(dev_index):
                 stream = torch.cuda.Stream()
                 nfl = _native.reduce_block_floats(G, n_loc, self.n_components, self.n_covariate_components, cov_levels)
@@ -268,6 +326,7 @@ class ALPINE:
                 stream.synchronize()
                 kw.update(stream=stream.cuda_stream, reduce_block=block.data_ptr())
                 assert stream.cuda_stream != 0
+
         def make_engine(dtype):
             e = _native.NativeShard(**{**kw, "x_dtype": dtype})
             try:
@@ -323,43 +382,60 @@ class ALPINE:
                 self.shard_comm_used = mode
             for i, y in enumerate(Y):
                 eng.upload_Y(i, np.ascontiguousarray(y[row0:row0 + n_loc].T))
-            eng.set_factors(W0, H0, B0, h_col0=c0)
-            if kw.get("batch_capacity", 0) > 0:
-                if sharded:
-                    with torch.cuda.device(dev_index), torch.cuda.stream(stream):
-                        self._run_epochs(eng, Y, N_total, n_iter, comm=comm, c0=c0, c1=c1,
-                                         gather_labels=dist if local_input else None)
-                else:
-                    self._run_epochs(eng, Y, N_total, n_iter)
-            elif sharded:
-                with torch.cuda.device(dev_index), torch.cuda.stream(stream):
-                    ShardedLoop(eng, comm, als_groups=(len(cov_levels) + 1 if self.use_als else 0)).run(n_iter, with_loss=True)
-            elif self.verbose:
-                # main.py:490-494, :669-671: tqdm bar with the objective loss.  The loop runs asynchronously on the device,
-                # so the bar advances in chunks (one host sync per chunk instead of one per iteration).
-                from tqdm import tqdm
-                step = max(1, n_iter // 20)
-                with tqdm(total=n_iter, desc="Iteration", ncols=100) as pbar:
-                    done = 0
-                    while done < n_iter:
-                        k = min(step, n_iter - done)
-                        eng.run(k, with_loss=True)
-                        done += k
-                        pbar.set_postfix({"objective loss": float(eng.losses()[-1, 0])})
-                        pbar.update(k)
-            else:
-                eng.run(n_iter, with_loss=True)
-            if scale:
-                eng.scale()
-            W, H_loc, Bs = eng.get_factors()
-            losses = eng.losses()
-            info = eng.info()
-            info_d = {f: getattr(info, f) for f, _ in info._fields_}
-        finally:
+        except BaseException:
             eng.close()
+            raise
+        return dict(eng=eng, comm=comm, block=block, stream=stream, dist=dist, rank=rank, world=world, sharded=sharded,
+                    local_input=local_input, dev_index=dev_index, N_total=N_total, G=G, c0=c0, c1=c1, n_loc=n_loc,
+                    cov_levels=cov_levels, Y=Y, x_dtype=x_dtype, batch_capacity=kw["batch_capacity"])
+
+    def _run_session(self, sess: dict, n_iter: int, scale: bool) -> dict:
+        """Initialise exactly like main.py:436-472, run the MU loop on the resident input, read the factors back."""
+        eng, comm, dist = sess["eng"], sess["comm"], sess["dist"]
+        sharded, local_input, dev_index, stream = sess["sharded"], sess["local_input"], sess["dev_index"], sess["stream"]
+        N_total, G, c0, c1, cov_levels, Y = sess["N_total"], sess["G"], sess["c0"], sess["c1"], sess["cov_levels"], sess["Y"]
+        W0, H0, B0 = draw_initial_factors(self.random_state, self.eps, G, N_total, self.n_all_components, cov_levels)
+        # The reference's loop also draws torch.randperm(N) once per iteration from the global generator
+        # (sampling.py:14).  Full batch makes the permutation a numerical no-op, so it is not applied, but a later
+        # unseeded transform() (main.py:687) continues that stream: remember how to advance it lazily.
+        self._rng_post_init = torch.get_rng_state()
+        self._rng_replay = (N_total, n_iter)
+        eng.set_factors(W0, H0, B0, h_col0=c0)
+        eng.reset_losses()
+        if sess["batch_capacity"] > 0:
+            if sharded:
+                with torch.cuda.device(dev_index), torch.cuda.stream(stream):
+                    self._run_epochs(eng, Y, N_total, n_iter, comm=comm, c0=c0, c1=c1,
+                                     gather_labels=dist if local_input else None)
+            else:
+                self._run_epochs(eng, Y, N_total, n_iter)
+        elif sharded:
+            with torch.cuda.device(dev_index), torch.cuda.stream(stream):
+                ShardedLoop(eng, comm, als_groups=(len(cov_levels) + 1 if self.use_als else 0)).run(n_iter, with_loss=True)
+        elif self.verbose:
+            # main.py:490-494, :669-671: tqdm bar with the objective loss.  The loop runs asynchronously on the device,
+            # so the bar advances in chunks (one host sync per chunk instead of one per iteration).
+            from tqdm import tqdm
+            step = max(1, n_iter // 20)
+            with tqdm(total=n_iter, desc="Iteration", ncols=100) as pbar:
+                done = 0
+                while done < n_iter:
+                    k = min(step, n_iter - done)
+                    eng.run(k, with_loss=True)
+                    done += k
+                    pbar.set_postfix({"objective loss": float(eng.losses()[-1, 0])})
+                    pbar.update(k)
+        else:
+            eng.run(n_iter, with_loss=True)
+        if scale:
+            eng.scale()
+        W, H_loc, Bs = eng.get_factors()
+        losses = eng.losses()
+        info = eng.info()
+        info_d = {f: getattr(info, f) for f, _ in info._fields_}
         if sharded and not local_input:
             H = np.empty((self.total_components, N_total), dtype=np.float32)
-            parts = [None] * world
+            parts = [None] * sess["world"]
             dist.all_gather_object(parts, (c0, c1, H_loc))
             for a, b, h in parts:
                 H[:, a:b] = h
@@ -432,19 +508,26 @@ class ALPINE:
                 raise
             return e
 
-        x_dtype = "split" if self.x_dtype == "auto" else self.x_dtype
-        try:
-            eng = make_engine(x_dtype)
-        except _native.AlpineNativeError as err:
-            if not (self.x_dtype == "auto" and err.code == -5):
-                raise
-            eng = make_engine("x3")
-        try:
-            eng.set_factors(W, H0, [])
-            eng.transform(n_iter)
-            _, H, _ = eng.get_factors()
-        finally:
-            eng.close()
+        resident = self._resident_engine_for(X) if (dist is None or self.shard_cells != "local") else None
+        if resident is not None:
+            # adata.X is the very matrix fit() left in HBM: one W^TX sweep on the resident copy, no upload
+            resident.set_factors(W, H0, self.matrices["Bs"])
+            resident.transform(n_iter)
+            _, H, _ = resident.get_factors()
+        else:
+            x_dtype = "split" if self.x_dtype == "auto" else self.x_dtype
+            try:
+                eng = make_engine(x_dtype)
+            except _native.AlpineNativeError as err:
+                if not (self.x_dtype == "auto" and err.code == -5):
+                    raise
+                eng = make_engine("x3")
+            try:
+                eng.set_factors(W, H0, [])
+                eng.transform(n_iter)
+                _, H, _ = eng.get_factors()
+            finally:
+                eng.close()
         offs = np.cumsum([0] + self.n_all_components)
         Hs = [H[offs[j]:offs[j + 1]] for j in range(len(self.n_all_components))]
         for i, covariate in enumerate(self.covariate_keys):
@@ -534,7 +617,7 @@ class ALPINE:
              [np.asarray(adata.varm["ALPINE_weights"], dtype=np.float32)]
         W = np.ascontiguousarray(np.concatenate(Ws, axis=1))
         H = np.ascontiguousarray(np.concatenate(Hs, axis=0))
-        recon_loss = self._recon_loss_device(np.asarray(adata.X), W, H)
+        recon_loss = self._recon_loss_device(adata.X if isinstance(adata.X, np.ndarray) else np.asarray(adata.X), W, H)
 
         def kl_divergence(y, y_hat):                                                   # main.py:200-204
             y_hat = np.clip(y_hat, a_min=self.eps, a_max=None)
@@ -555,6 +638,10 @@ class ALPINE:
         if dev_index < 0:
             dev_index = torch.cuda.current_device()
         n_sample, G = X_cells_genes.shape
+        resident = self._resident_engine_for(X_cells_genes)
+        if resident is not None and W.shape[1] == self.total_components:
+            resident.set_factors(W, H, self.matrices["Bs"])          # adata.X is still in HBM from fit(): no upload
+            return float(resident.eval_recon_direct())
         eng = _native.NativeShard(n_genes=G, n_cells=n_sample, n_components=W.shape[1], cov_components=[], cov_levels=[], lam=[],
                                   eps=self.eps, device_id=dev_index, transform_only=True, x_dtype="f32")
         try:
