@@ -5,23 +5,27 @@
 # One run with --kernel-trace --stats (per-kernel durations) and one run per counter group (PMC passes are never
 # combined with other traces).  Copy the files you want judged into profiles/rNN/.
 set -e
+#   bash tools/profile_mode.sh x3 cfg3 fullsig --x-scale 0.3712345     (tag + extra bench.py arguments: file names get <mode>_<tag>)
 MODE=${1:-x3}
 WL=${2:-cfg3}
+TAG=${3:-}
+EXTRA="${@:4}"
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
-RAW=$OUT/raw_${WL}_${MODE}
+MT=$MODE${TAG:+_$TAG}
+RAW=$OUT/raw_${WL}_${MT}
 mkdir -p "$RAW"
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--workload $WL --dtype $MODE --no-cpu-baseline --no-other-modes"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -- python3 "$ROOT/bench.py" $COMMON --steps 20 --warmup 3 > "$OUT/${WL}_${MODE}_kernel_stats_bench.json" 2> "$RAW/stats.err"
+COMMON="--workload $WL --dtype $MODE --no-cpu-baseline --no-other-modes $EXTRA"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -- python3 "$ROOT/bench.py" $COMMON --steps 20 --warmup 3 > "$OUT/${WL}_${MT}_kernel_stats_bench.json" 2> "$RAW/stats.err"
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/fetch" -- python3 "$ROOT/bench.py" $COMMON --steps 3 --warmup 1 > /dev/null 2> "$RAW/fetch.err"
 echo "FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/write" -- python3 "$ROOT/bench.py" $COMMON --steps 3 --warmup 1 > /dev/null 2> "$RAW/write.err"
 echo "WRITE_SIZE pass done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$RAW/sq" -- python3 "$ROOT/bench.py" $COMMON --steps 3 --warmup 1 > /dev/null 2> "$RAW/sq.err"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$RAW/sq" -- python3 "$ROOT/bench.py" $COMMON --steps 3 --warmup 1 > /dev/null 2> "$RAW/sq.err"
 echo "SQ pass done"
 cd "$ROOT"
-python3 tools/summarize_pmc.py "$RAW" "$OUT" "$WL" "$MODE"
+python3 tools/summarize_pmc.py "$RAW" "$OUT" "$WL" "$MT"
 rm -rf "$RAW"

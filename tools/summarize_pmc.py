@@ -51,6 +51,7 @@ def main():
     write_kb = groups["write"][(k, "WRITE_SIZE")][0]
     busy = groups["sq"].get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), (0.0, 0))[0]
     gui = groups["sq"].get((k, "GRBM_GUI_ACTIVE"), (0.0, 0))[0]
+    sq = {n: groups["sq"].get((k, n), (None, 0))[0] for n in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES")}
     rd = 2.0 * fetch_kb * 1024.0                    # gfx950: FETCH_SIZE reports half of a 16 B/lane coalesced stream
     wr = write_kb * 1024.0
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]
@@ -64,6 +65,7 @@ def main():
         "traffic_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (rd + wr) / alg,
         "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_XCD": gui,
         "mfma_busy_fraction": busy / (gui * 128.0) if gui else None,     # per-SIMD busy cycles / (per-XCD active cycles x 32 CUs x 4 SIMDs)
+        "sq_counters_per_launch": sq,      # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
         "avg_launch_ms_kernel_trace": None,
         "note": "FETCH_SIZE doubled (gfx950); the counter sees fabric reads (HBM + MALL hits), i.e. X plus the operand-panel re-reads",
     }
@@ -75,6 +77,9 @@ def main():
                     summary["kernel_trace_calls"] = int(row["Calls"])
                     break
     tag = "" if mode == "f32" else f"_{mode}"
+    if stats and summary["avg_launch_ms_kernel_trace"] and gui:
+        # DVFS note of MI355X_MICROARCH.md: effective shader clock ~ GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time
+        summary["effective_clock_GHz_from_GRBM"] = gui / 8.0 / (summary["avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
     with open(os.path.join(out, f"{wl}{tag}_stream_gemm_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print(json.dumps(summary))
