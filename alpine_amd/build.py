@@ -36,7 +36,10 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), di
     if not force and not is_stale(lib):
         return lib
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", *(("-DALPINE_DIAGNOSTICS",) if diagnostics else ()), *extra_flags,
+           "-Wall", "-Wno-unused-function",
+           # no SLP vectorisation: v_pk_add_f32 / v_pk_fma_f32 formed from adjacent scalar float ops are slower than the
+           # scalar forms beside MFMAs (MI355X_MICROARCH.md, filler prices) and need register pairs (v_mov copies)
+           "-fno-slp-vectorize", *(("-DALPINE_DIAGNOSTICS",) if diagnostics else ()), *extra_flags,
            "-o", lib, SRC, f"-L{ROCM_LIB}", "-lrccl", f"-Wl,-rpath,{ROCM_LIB}"]
     if verbose:
         print(" ".join(cmd))

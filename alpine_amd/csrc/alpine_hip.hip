@@ -114,6 +114,7 @@ struct alpine_ctx {
     bool use_als = false;
     bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
+    int x3_variant = 0;               // env ALPINE_HIP_X3_VARIANT: instruction schedule of the x3 sweep (A/B; results bit-identical)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ALPINE_KERNEL_COUNT];
@@ -273,6 +274,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     if (const char* e = std::getenv("ALPINE_HIP_X3_ABLATE")) c->x3_ablate = std::atoi(e);
 #endif
     if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
+    if (const char* e = std::getenv("ALPINE_HIP_X3_VARIANT")) c->x3_variant = std::atoi(e);
     if (const char* e = std::getenv("ALPINE_HIP_H_UPDATE")) c->h_update_valu = (std::strcmp(e, "valu") == 0);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -760,7 +762,8 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
                 if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
 #endif
-                hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                if (c->x3_variant == 1) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 4>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
             default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;

@@ -934,6 +934,31 @@ __device__ __forceinline__ void tile_load_cd(const float* __restrict__ src, floa
     wave_lds_fence();
 }
 
+// The same in two halves, so that the global loads of several tiles can be in flight before the first LDS exchange:
+// tile_load_issue (rows -> raw registers: lane L of instruction i holds the 16 bytes at float offset 4*(64 i + L)) and
+// tile_raw_to_cd (raw registers -> C/D registers through the wave's scratch).
+template <int KT>
+__device__ __forceinline__ void tile_load_issue(const float* __restrict__ src, int lane, f32x4 (&raw)[(32 * KT * 8) / 64])
+{
+    constexpr int NI = (32 * KT * 8) / 64;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) raw[i] = *reinterpret_cast<const f32x4*>(src + 4 * (64 * i + lane));
+}
+
+template <int KT>
+__device__ __forceinline__ void tile_raw_to_cd(const f32x4 (&raw)[(32 * KT * 8) / 64], float* __restrict__ tr, int lane, f32x4 (&out)[KT][4])
+{
+    constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4, NI = (32 * Q4) / 64;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = 64 * i + lane;
+        *reinterpret_cast<f32x4*>(&tr[(idx / Q4) * LD + 4 * (idx % Q4)]) = raw[i];
+    }
+    wave_lds_fence();
+    tile_lds_to_cd<KT>(tr, lane & 31, lane >> 5, out);
+    wave_lds_fence();
+}
+
 // C/D registers -> tile rows (contiguous at dst), rows >= rows_valid are not written
 template <int KT>
 __device__ __forceinline__ void tile_store_cd(float* __restrict__ dst, float* __restrict__ tr, int lane, const f32x4 (&in)[KT][4], int rows_valid)
@@ -968,23 +993,24 @@ __device__ __forceinline__ void sg_sum_pieces_rows(const float* __restrict__ pie
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] = *reinterpret_cast<const f32x4*>(base + 4 * (64 * i + lane));
     }
-    // two pieces (2 * NI 1-KiB loads per wave) in flight per trip: on the fixed stream-K grid a tile has ~10 pieces at
+    // UNR pieces (UNR * NI 1-KiB loads per wave) in flight per trip: on the fixed stream-K grid a tile has ~10 pieces at
     // every shard size and a trip per piece costs one full memory latency; the adds stay in ascending workgroup order
+    constexpr int UNR = KT <= 2 ? 4 : 2;
     int w = w_lo + 1;
-    for (; w + 1 <= w_hi; w += 2) {
-        const float* b0 = pieces + sg_piece_offset_inner(g, w, KP) + (int64_t)fl0 * KP;
-        const float* b1 = pieces + sg_piece_offset_inner(g, w + 1, KP) + (int64_t)fl0 * KP;
-        f32x4 v0[NI], v1[NI];
+    for (; w + UNR - 1 <= w_hi; w += UNR) {
+        f32x4 v[UNR][NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) v0[i] = *reinterpret_cast<const f32x4*>(b0 + 4 * (64 * i + lane));
+        for (int u = 0; u < UNR; ++u) {
+            const float* bu = pieces + sg_piece_offset_inner(g, w + u, KP) + (int64_t)fl0 * KP;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) v1[i] = *reinterpret_cast<const f32x4*>(b1 + 4 * (64 * i + lane));
+            for (int i = 0; i < NI; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(bu + 4 * (64 * i + lane));
+        }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] += v0[i];
+        for (int u = 0; u < UNR; ++u)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] += v1[i];
+            for (int i = 0; i < NI; ++i) acc[i] += v[u][i];
     }
-    if (w <= w_hi) {
+    for (; w <= w_hi; ++w) {
         const float* base = pieces + sg_piece_offset_inner(g, w, KP) + (int64_t)fl0 * KP;
         f32x4 v[NI];
 #pragma unroll
@@ -1093,8 +1119,12 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
 
             // whole-row global accesses, C/D layout in registers (rows n0 .. n0+31 exist: H and the pieces are padded to 128 rows)
             f32x4 hreg[KT][4], xreg[KT][4];
-            sg_sum_pieces_rows<KT>(pieces, g, ft, fl0, w_lo, w_hi, tr, lane, xreg);
-            tile_load_cd<KT>(H + n0 * KP, tr, lane, hreg);
+            {
+                f32x4 hraw[(32 * KT * 8) / 64];
+                tile_load_issue<KT>(H + n0 * KP, lane, hraw);          // in flight behind the pieces' loads
+                sg_sum_pieces_rows<KT>(pieces, g, ft, fl0, w_lo, w_hi, tr, lane, xreg);
+                tile_raw_to_cd<KT>(hraw, tr, lane, hreg);
+            }
 
             f32x16 acc[KT];
 #pragma unroll
@@ -1225,8 +1255,13 @@ void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, 
     const bool valid = g < G;
     // W and XH^T are padded to 128 rows: the wave's 32 rows exist; whole-row loads, C/D layout in registers
     f32x4 wreg[KT][4], xreg[KT][4];
-    tile_load_cd<KT>(W + g0 * KP, tr, lane, wreg);
-    tile_load_cd<KT>(XHt + g0 * KP, tr, lane, xreg);
+    {
+        f32x4 wraw[(32 * KT * 8) / 64], xraw[(32 * KT * 8) / 64];
+        tile_load_issue<KT>(W + g0 * KP, lane, wraw);
+        tile_load_issue<KT>(XHt + g0 * KP, lane, xraw);
+        tile_raw_to_cd<KT>(wraw, tr, lane, wreg);
+        tile_raw_to_cd<KT>(xraw, tr, lane, xreg);
+    }
     double dacc = 0.0;
 #pragma unroll
     for (int m = 0; m < KT; ++m)

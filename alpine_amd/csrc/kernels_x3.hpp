@@ -47,6 +47,22 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 (&b)[3])
     }
 }
 
+// The same split written on scalars: no float2 temporaries, so the compiler neither needs register pairs (v_mov copies) nor
+// forms v_pk_add_f32 (slow beside MFMAs); 11 single-issue VALU ops per pair of values.  Bit-identical to x3_split8.
+__device__ __forceinline__ unsigned x3_cvt2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bf16x2v)); }
+__device__ __forceinline__ void x3_split8_scalar(const float (&v)[8], u32x4 (&b)[3])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = v[2 * q], x1 = v[2 * q + 1];
+        const unsigned hi = x3_cvt2(x0, x1);
+        const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+        const unsigned mid = x3_cvt2(r0, r1);
+        const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+        b[0][q] = hi; b[1][q] = mid; b[2][q] = x3_cvt2(s0, s1);
+    }
+}
+
 // One panel stage = X3_RING k-steps.  Per k-step: A fragments of all three panel planes (double-buffered over k-steps),
 // then per 128-column half: 4 x (split one tile's 8 x float32 into planes, 6*KT MFMAs), then the half's 8 loads are
 // re-issued for the same k-step of the next stage.
@@ -84,6 +100,8 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
 #pragma unroll
                     for (int q = 0; q < 3; ++q) b[q] = u32x4{__float_as_uint(v[0]) + __float_as_uint(v[1]), __float_as_uint(v[2]) + __float_as_uint(v[3]),
                                                              __float_as_uint(v[4]) + __float_as_uint(v[5]), __float_as_uint(v[6]) + __float_as_uint(v[7])};
+                } else if constexpr (ABL == 4) {
+                    x3_split8_scalar(v, b);
                 } else {
                     x3_split8(v, b);
                 }
@@ -97,6 +115,18 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
                 // products with the mid / lo planes: nothing to add when the whole 16 x 32 tile of X is exactly one bf16
                 // plane (small integer counts, zeros) -- a wave-uniform test, no loads inside the branch
                 const unsigned rest = (b[1][0] | b[1][1] | b[1][2] | b[1][3]) & 0x7fff7fffu;
+                if constexpr (ABL == 4) {
+                    // issue order of this basic block: the hi conversions, then one MFMA followed by 5 of the VALU ops that
+                    // form the mid plane (and the zero test) ... so that every MFMA gap carries work and none carries
+                    // more than hides beside a 32-cycle MFMA (left alone the compiler packs 7-8 into the first gaps, 0 into the last)
+                    __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+#pragma unroll
+                    for (int i = 0; i < 3 * KT - 1; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, (24 + 3 * KT - 2) / (3 * KT - 1), 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                }
                 if (ABL != 3 && __builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp)
@@ -108,6 +138,15 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
                     for (int m = 0; m < KT; ++m)
                         acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][0][m]),
                                                                                      __builtin_bit_cast(bf16x8, b[2]), acc[m][4 * hf + t], 0, 0, 0);
+                    if constexpr (ABL == 4) {
+                        // the lo plane (20 VALU ops) spread over the gaps of this block's 3 KT MFMAs
+#pragma unroll
+                        for (int i = 0; i < 3 * KT - 1; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, (20 + 3 * KT - 2) / (3 * KT - 1), 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -182,7 +221,7 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
                 const int si = tid + NT * v;
                 if (SETS % NT == 0 || si < SETS) {
                     u32x4 o[3];
-                    x3_split8(pf[v], o);
+                    if constexpr (ABL == 4) x3_split8_scalar(pf[v], o); else x3_split8(pf[v], o);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&lds[b][q * STAGE_BF16 + 8 * si]) = o[q];
                 }
@@ -240,11 +279,11 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            x3_stage<KT, NH, false>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
+            x3_stage<KT, NH, false, (ABL == 4 ? 4 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
             __syncthreads();
             ++t;
         }
-        x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
+        x3_stage<KT, NH, true, (ABL == 4 ? 4 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
         float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;
