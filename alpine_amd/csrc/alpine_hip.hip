@@ -762,7 +762,8 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
                 if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
 #endif
-                if (c->x3_variant == 1) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 4>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                if (c->x3_variant == 2) hipLaunchKernelGGL((stream_gemm_x3w_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else if (c->x3_variant == 1) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 4>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;

@@ -301,4 +301,235 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// The same sweep on v_mfma_f32_16x16x32_bf16 ("x3w").  Same X stream (float32, one global_load_dwordx4 per lane and row),
+// same in-register split, same six plane products, same pieces -- only the matrix instruction differs: 16 x 16 output
+// tiles with a 32-deep contraction instead of 32 x 32 x 16.  MFMA cycles per element are identical (16 cycles per 16x16x32
+// vs 32 per 32x32x16), but a 16 x 16 accumulator tile is read and written 256 values per 8192 multiply-adds instead of
+// 1024 per 16384, and on data with full significands -- where the chip lowers its clock under the matrix load
+// (MI355X_MICROARCH.md, "DVFS give-back" item 7) -- the chip holds a higher clock on this shape.  Results are NOT
+// bitwise those of the 32x32x16 form (the order in which a row's 16 / 32 products are added differs); same accuracy.
+//
+// Lane (c16 = lane & 15, kg = lane >> 4).  B operand of tile t of a 64-column group: rows r + 8 kg + j (j = 0..7) of column
+// f_cg + 4 c16 + t -> one float4 per row feeds the group's four interleaved 16-column tiles; a wave covers 32 rows x 64
+// columns with 8 loads (256-byte row segments).  A operand: components 16 m + c16, the same 8 rows, from the k-packed
+// LDS image [row / 8][component][row % 8].  One panel stage = one k-step of 32 rows; the X registers hold ONE k-step
+// (32 KiB per wave, as before), each 64-column group refilled for the next k-step right after its last split.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int KT>
+__device__ __forceinline__ void sg_flush_tile16(float* __restrict__ tr, const f32x4 (&d)[2 * KT], float* __restrict__ out_row0,
+                                                int64_t row_stride, int lane)
+{
+    // 16 columns x KP components in C/D layout (lane (c16, kg) holds components 16 m + 4 kg + e of column c16) -> 16 rows of a
+    // piece with whole-row stores, through a wave-private scratch tr[16][KP + 4]
+    constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4, M16 = 2 * KT;
+    const int c16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < M16; ++m) *reinterpret_cast<f32x4*>(&tr[c16 * LD + 16 * m + 4 * kg]) = d[m];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < (16 * Q4) / 64; ++i) {
+        const int idx = i * 64 + lane, r = idx / Q4, c4 = idx % Q4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&tr[r * LD + 4 * c4]);
+        *reinterpret_cast<f32x4*>(out_row0 + (int64_t)r * row_stride + 4 * c4) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int KT, int NH>
+__global__ __launch_bounds__(256, 1)
+void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
+                            int64_t ldS, SweepGeom g)
+{
+    static_assert(KT * NH <= 4, "256 accumulator registers per lane");
+    constexpr int KP = 32 * KT, M16 = 2 * KT;
+    constexpr int WAVE_F = 128 * NH, BLOCK_F = 4 * WAVE_F, NCG = 2 * NH;       // 64-column groups per wave
+    constexpr int NT = 256;
+    constexpr int ROWS = 32;                                          // rows per k-step = per panel stage
+    static_assert(SG_ROW_ALIGN % ROWS == 0, "stream-K spans are multiples of one stage");
+    constexpr int STAGE_BF16 = ROWS * KP;
+    constexpr int SETS = (ROWS / 8) * KP;
+    constexpr int PVS = (SETS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * STAGE_BF16];
+    __shared__ __attribute__((aligned(16))) float flush_tr[4][16 * (KP + 4)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int w = blockIdx.x;
+    const int64_t total = (int64_t)g.nft * g.R;
+    int64_t pos = (int64_t)w * g.L;
+    const int64_t pos_end = min(total, pos + g.L);
+    const int first_tile = (int)(pos / g.R);
+
+    float pf[PVS][8];
+    f32x4 x[NCG][8];
+
+    while (pos < pos_end) {
+        const int ft = (int)(pos / g.R);
+        const int r_begin = (int)(pos - (int64_t)ft * g.R);
+        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
+        pos += r_end - r_begin;
+        const int nst = (r_end - r_begin) / ROWS;
+        const int f0 = (ft * 4 + wave) * WAVE_F;
+        const bool active = f0 < g.F;
+        // F is a multiple of 128, not of 256: a wave whose second half lies outside re-reads its first half there (valid
+        // memory; those accumulators are never written out)
+        const bool half2 = NH == 2 && f0 + 128 < g.F;
+
+        const float* pfptr = Pf + (int64_t)r_begin * KP;
+        auto load_p = [&](int t) {
+#pragma unroll
+            for (int v = 0; v < PVS; ++v) {
+                const int si = tid + NT * v;                        // set index = rb * KP + col
+                if (SETS % NT == 0 || si < SETS) {
+                    const int rb = si / KP, col = si % KP;
+                    const float* src = pfptr + ((int64_t)t * ROWS + 8 * rb) * KP + col;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[v][e] = src[e * KP];
+                }
+            }
+        };
+        auto store_p = [&](int b) {
+#pragma unroll
+            for (int v = 0; v < PVS; ++v) {
+                const int si = tid + NT * v;
+                if (SETS % NT == 0 || si < SETS) {
+                    u32x4 o[3];
+                    x3_split8_scalar(pf[v], o);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&lds[b][q * STAGE_BF16 + 8 * si]) = o[q];
+                }
+            }
+        };
+
+        __syncthreads();
+        load_p(0);
+        store_p(0);
+        if (nst > 1) load_p(1);
+
+        if (!active) {
+            __syncthreads();
+            for (int t = 0; t + 1 < nst; ++t) {
+                store_p((t + 1) & 1);
+                if (t + 2 < nst) load_p(t + 2);
+                __syncthreads();
+            }
+            continue;
+        }
+
+        f32x4 acc[M16][4 * NCG];
+#pragma unroll
+        for (int m = 0; m < M16; ++m)
+#pragma unroll
+            for (int j = 0; j < 4 * NCG; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // this lane's float4 of row r_begin + 8 kg (+ e), columns f_cg + 4 c16 .. + 3 (element t -> tile t, column c16)
+        const float* xbase[NCG];
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) {
+            const int fcg = (cg >= 2 && !half2) ? f0 + 64 * (cg - 2) : f0 + 64 * cg;
+            xbase[cg] = S + (int64_t)(r_begin + 8 * kg) * ldS + fcg + 4 * c16;
+        }
+        const int64_t x_stage = (int64_t)ROWS * ldS;
+        const int lds_lane = (kg * KP + c16) * 8;
+
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                x[cg][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase[cg] + (int64_t)e * ldS));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+
+        // one stage: A fragments of the three panel planes, then per 64-column group: 4 x (split one tile's 8 float32 into
+        // planes, 6 * M16 MFMAs), then the group's 8 loads are re-issued for the next stage
+        auto stage = [&](const unsigned short* __restrict__ lrow, int t_next, bool last) {
+            u32x4 a[3][M16];
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int m = 0; m < M16; ++m)
+                    a[pp][m] = *reinterpret_cast<const u32x4*>(lrow + pp * STAGE_BF16 + (16 * m) * 8);
+#pragma unroll
+            for (int cg = 0; cg < NCG; ++cg) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = x[cg][e][t];
+                    u32x4 b[3];
+                    x3_split8_scalar(v, b);
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                        for (int m = 0; m < M16; ++m)
+                            acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
+                                                                                         __builtin_bit_cast(bf16x8, b[0]), acc[m][4 * cg + t], 0, 0, 0);
+                    // mid / lo planes of X: nothing to add when the whole 32 x 16 tile is exactly one bf16 plane (wave-uniform test)
+                    const unsigned rest = (b[1][0] | b[1][1] | b[1][2] | b[1][3]) & 0x7fff7fffu;
+                    if (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                            for (int m = 0; m < M16; ++m)
+                                acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
+                                                                                             __builtin_bit_cast(bf16x8, b[1]), acc[m][4 * cg + t], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < M16; ++m)
+                            acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]),
+                                                                                         __builtin_bit_cast(bf16x8, b[2]), acc[m][4 * cg + t], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!last) {
+                    const float* src = xbase[cg] + (int64_t)t_next * x_stage;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[cg][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (int64_t)e * ldS));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        int t = 0;
+        for (; t + 2 < nst; ++t) {
+            store_p((t + 1) & 1);
+            load_p(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(&lds[t & 1][lds_lane], t + 1, false);
+            __syncthreads();
+        }
+        if (t + 1 < nst) {
+            store_p((t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(&lds[t & 1][lds_lane], t + 1, false);
+            __syncthreads();
+            ++t;
+        }
+        stage(&lds[t & 1][lds_lane], 0, true);
+
+        // D: component = 16 m + 4 kg + e, column = c16 -> f_local = WAVE_F * wave + 64 cg + 4 c16 + t
+        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) {
+            if (cg >= 2 && !half2) break;                  // second half outside F: nothing to write
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 d[M16];
+#pragma unroll
+                for (int m = 0; m < M16; ++m) d[m] = acc[m][4 * cg + tt];
+                sg_flush_tile16<KT>(flush_tr[wave], d, out + (int64_t)(64 * cg + tt) * KP, 4 * KP, lane);
+            }
+        }
+    }
+}
+
 }  // namespace alpine
