@@ -114,7 +114,9 @@ struct alpine_ctx {
     bool use_als = false;
     bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
-    int x3_variant = 0;               // env ALPINE_HIP_X3_VARIANT: instruction schedule of the x3 sweep (A/B; results bit-identical)
+    int x3_variant = -1;              // env ALPINE_HIP_X3_VARIANT: 0 = 32x32x16 MFMA, 2 = 16x16x32 (x3w), unset = chosen from the data
+    bool x3_wide = false;             // the sweeps use stream_gemm_x3w_kernel (decided in alpine_finalize_X)
+    double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ALPINE_KERNEL_COUNT];
@@ -436,6 +438,9 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     info->reduce_block_floats = c->red_floats;
     info->device_bytes = (int64_t)c->bytes;
     info->x_sqnorm = c->xnorm2;
+    info->x_multi_plane_fraction = c->x_multi_plane_frac;
+    info->x3_wide = c->x3 && c->x3_wide ? 1 : 0;
+    info->reserved = 0;
     return 0;
 }
 
@@ -599,6 +604,18 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
     HIPCHK(c, hipGetLastError());
     int rc = sum_f64_partials(c, blocks, &c->xnorm2);
     if (rc) return rc;
+    if (!c->bf16) {
+        // Which matrix instruction the x3 sweeps use is decided by the data: on count-like X (every element one bf16 plane:
+        // the mid / lo products are skipped) the sweep is memory-bound and the 32x32x16 form is ~1.5 % faster; on X with full
+        // significands all six products run, the chip lowers its clock under the matrix load, and the 16x16x32 form (x3w)
+        // holds a higher clock: ~5 % faster.  Both are float32-grade; they differ in summation order only.
+        std::vector<double> h(2 * (size_t)blocks);
+        HIPCHK(c, hipMemcpy(h.data(), c->f64part, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        double multi = 0;
+        for (int b = 0; b < blocks; ++b) multi += h[(size_t)blocks + b];
+        c->x_multi_plane_frac = multi / ((double)c->G * (double)c->N);
+        c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && c->x_multi_plane_frac > 0.01);
+    }
     c->x_final = true;
     return 0;
 }
@@ -754,6 +771,16 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     if (c->x3) {
         SweepGeom gx = g;
         if (c->ablate_flush) gx.panel_fixed = 2;
+        if (c->x3_wide && !c->x3_ablate) {
+            switch (c->KT) {
+                case 1: hipLaunchKernelGGL((stream_gemm_x3w_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+                case 2: hipLaunchKernelGGL((stream_gemm_x3w_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+                case 3: hipLaunchKernelGGL((stream_gemm_x3w_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+                default: hipLaunchKernelGGL((stream_gemm_x3w_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            }
+            HIPCHK(c, hipGetLastError());
+            return 0;
+        }
         switch (c->KT) {
             case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
             case 2:
@@ -762,9 +789,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
                 if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
 #endif
-                if (c->x3_variant == 2) hipLaunchKernelGGL((stream_gemm_x3w_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else if (c->x3_variant == 1) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 4>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
             default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;

@@ -1528,19 +1528,26 @@ void transpose_kernel(const float* __restrict__ src, int64_t ld_src, float* __re
 __global__ __launch_bounds__(256)
 void sqnorm_kernel(const float* __restrict__ x, int64_t n4, double* __restrict__ part)
 {
+    // part[block] = sum of squares; part[gridDim.x + block] = number of elements that are NOT exactly one bf16 plane (low 16
+    // bits of the float32 non-zero): the census behind the choice of the x3 sweep's matrix instruction
     __shared__ double red[256];
+    __shared__ double red2[256];
     double a = 0.0;
+    unsigned long long multi = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         a += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) multi += (__float_as_uint(v[e]) & 0xffffu) != 0u;
     }
     red[threadIdx.x] = a;
+    red2[threadIdx.x] = (double)multi;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        if (threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; red2[threadIdx.x] += red2[threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) { part[blockIdx.x] = red[0]; part[gridDim.x + blockIdx.x] = red2[0]; }
 }
 
 // pack / unpack between the caller's (row-major, unpadded) factors and the padded device layouts

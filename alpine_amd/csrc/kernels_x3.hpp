@@ -47,8 +47,10 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 (&b)[3])
     }
 }
 
-// The same split written on scalars: no float2 temporaries, so the compiler neither needs register pairs (v_mov copies) nor
-// forms v_pk_add_f32 (slow beside MFMAs); 11 single-issue VALU ops per pair of values.  Bit-identical to x3_split8.
+// The same split written on scalars (used by the 16x16x32 form below): no float2 temporaries, so the compiler neither needs
+// register pairs (v_mov copies) nor forms v_pk_add_f32; 11 single-issue VALU ops per pair of values.  Same values as x3_split8.
+// (A/B on the 32x32x16 kernel, together with sched_group_barrier interleaves of the split between the MFMAs: 0.4 - 2 %
+// SLOWER than the compiler's own schedule of the float2 form, so that kernel keeps x3_split8.)
 __device__ __forceinline__ unsigned x3_cvt2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bf16x2v)); }
 __device__ __forceinline__ void x3_split8_scalar(const float (&v)[8], u32x4 (&b)[3])
 {
@@ -100,8 +102,6 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
 #pragma unroll
                     for (int q = 0; q < 3; ++q) b[q] = u32x4{__float_as_uint(v[0]) + __float_as_uint(v[1]), __float_as_uint(v[2]) + __float_as_uint(v[3]),
                                                              __float_as_uint(v[4]) + __float_as_uint(v[5]), __float_as_uint(v[6]) + __float_as_uint(v[7])};
-                } else if constexpr (ABL == 4) {
-                    x3_split8_scalar(v, b);
                 } else {
                     x3_split8(v, b);
                 }
@@ -115,18 +115,6 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
                 // products with the mid / lo planes: nothing to add when the whole 16 x 32 tile of X is exactly one bf16
                 // plane (small integer counts, zeros) -- a wave-uniform test, no loads inside the branch
                 const unsigned rest = (b[1][0] | b[1][1] | b[1][2] | b[1][3]) & 0x7fff7fffu;
-                if constexpr (ABL == 4) {
-                    // issue order of this basic block: the hi conversions, then one MFMA followed by 5 of the VALU ops that
-                    // form the mid plane (and the zero test) ... so that every MFMA gap carries work and none carries
-                    // more than hides beside a 32-cycle MFMA (left alone the compiler packs 7-8 into the first gaps, 0 into the last)
-                    __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
-#pragma unroll
-                    for (int i = 0; i < 3 * KT - 1; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x2, (24 + 3 * KT - 2) / (3 * KT - 1), 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                }
                 if (ABL != 3 && __builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp)
@@ -138,15 +126,6 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
                     for (int m = 0; m < KT; ++m)
                         acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][0][m]),
                                                                                      __builtin_bit_cast(bf16x8, b[2]), acc[m][4 * hf + t], 0, 0, 0);
-                    if constexpr (ABL == 4) {
-                        // the lo plane (20 VALU ops) spread over the gaps of this block's 3 KT MFMAs
-#pragma unroll
-                        for (int i = 0; i < 3 * KT - 1; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, (20 + 3 * KT - 2) / (3 * KT - 1), 0);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -221,7 +200,7 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
                 const int si = tid + NT * v;
                 if (SETS % NT == 0 || si < SETS) {
                     u32x4 o[3];
-                    if constexpr (ABL == 4) x3_split8_scalar(pf[v], o); else x3_split8(pf[v], o);
+                    x3_split8(pf[v], o);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&lds[b][q * STAGE_BF16 + 8 * si]) = o[q];
                 }
@@ -279,11 +258,11 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            x3_stage<KT, NH, false, (ABL == 4 ? 4 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
+            x3_stage<KT, NH, false>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
             __syncthreads();
             ++t;
         }
-        x3_stage<KT, NH, true, (ABL == 4 ? 4 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
+        x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
         float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;

@@ -109,6 +109,9 @@ typedef struct {
     int64_t reduce_block_floats;
     int64_t device_bytes;           /* total device memory held by the ctx */
     double x_sqnorm;                /* ||X_local||_F^2 (valid after alpine_finalize_X) */
+    double x_multi_plane_fraction;  /* fraction of the elements of X that are not exactly one bf16 plane (float32 storage; after alpine_finalize_X) */
+    int32_t x3_wide;                /* 1: the x3 sweeps run on v_mfma_f32_16x16x32_bf16 (full-significand data), 0: on 32x32x16 (count-like data) */
+    int32_t reserved;
 } alpine_info;
 
 /* Number of floats in the per-iteration reduce block for a configuration (so a caller can allocate

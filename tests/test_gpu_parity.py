@@ -686,3 +686,126 @@ def test_verbose_progress_bar_does_not_change_results(capsys):
     assert np.array_equal(loud.loss_history.to_numpy(), quiet.loss_history.to_numpy())
     for a, b in zip(loud.matrices["Hs"], quiet.matrices["Hs"]):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- round-2 hardening
+def test_X_coverage_is_tracked_per_cell_interval():
+    """alpine_finalize_X needs every cell exactly covered: uploading one chunk twice does not stand in for a missing one."""
+    nat = _native()
+    c = load_case("kl_1cov")
+    p = c.params
+    n = c.X.shape[0]
+    eng = nat.NativeShard(n_genes=c.X.shape[1], n_cells=n, n_components=p["n_components"], cov_components=p["n_covariate_components"],
+                          cov_levels=[y.shape[0] for y in c.Ys], lam=p["lam"], x_dtype="x3")
+    half = n // 2
+    eng.upload_X_host(c.X[:half], cell0=0)
+    eng.upload_X_host(c.X[:half], cell0=0)              # the same chunk again: n cells "uploaded", half of them missing
+    with pytest.raises(nat.AlpineNativeError) as ei:
+        eng.finalize_X()
+    assert ei.value.code == -4 and f"first missing cell: {half}" in str(ei.value)
+    eng.upload_X_host(c.X[half - 3:], cell0=half - 3)   # overlapping chunks are fine (the overlap is overwritten)
+    eng.finalize_X()
+    for i, y in enumerate(c.Ys):
+        eng.upload_Y(i, y)
+    eng.set_factors(c.W0, c.H0, c.B0)
+    eng.run(1, with_loss=False)
+    W, H, _ = eng.get_factors()
+    assert rel_fro(W, c.W1) < 1e-5 and rel_fro(H, c.H1) < 1e-5
+    eng.close()
+
+
+def test_split_ctx_refuses_uploads_after_its_second_plane_was_released():
+    nat = _native()
+    c = load_case("counts_2cov")                        # integer counts: one exact bf16 plane
+    p = c.params
+    eng = nat.NativeShard(n_genes=c.X.shape[1], n_cells=c.X.shape[0], n_components=p["n_components"],
+                          cov_components=p["n_covariate_components"], cov_levels=[y.shape[0] for y in c.Ys], lam=p["lam"], x_dtype="split")
+    eng.upload_X_host(c.X)
+    eng.finalize_X()
+    with pytest.raises(nat.AlpineNativeError) as ei:
+        eng.upload_X_host(c.X)
+    assert ei.value.code == -4 and "second plane" in str(ei.value)
+    eng.close()
+
+
+def test_production_library_ignores_the_ablation_environment(monkeypatch):
+    """The timing-only ablations (wrong results by design) exist only in the diagnostics build; a stray environment
+    variable must not change what the production library computes."""
+    c = load_case("counts_2cov")
+    base = make_engine(c, x_dtype="x3")
+    base.run(3, with_loss=True)
+    want = (base.get_factors(), base.losses())
+    base.close()
+    for name in ("ALPINE_HIP_ABLATE_STRIDE0", "ALPINE_HIP_ABLATE_PANEL", "ALPINE_HIP_ABLATE_FLUSH", "ALPINE_HIP_X3_ABLATE"):
+        monkeypatch.setenv(name, "1")
+    eng = make_engine(c, x_dtype="x3")
+    eng.run(3, with_loss=True)
+    got = (eng.get_factors(), eng.losses())
+    eng.close()
+    assert np.array_equal(got[0][0], want[0][0]) and np.array_equal(got[0][1], want[0][1]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("knob", ["ALPINE_HIP_NO_TAIL", "ALPINE_HIP_FUSED_W", "ALPINE_HIP_UNFUSED_MID"])
+def test_fused_tails_equal_the_separate_kernels(knob, monkeypatch):
+    """The H update's tail (H H^T partials + covariate statistics of the updated H) and the W update's tail (W^T W partials)
+    against the stand-alone kernels they replace: same inputs, same per-block arithmetic -> results to float32 rounding of a
+    different partial-sum grouping, loss rows included."""
+    for name in ("kl_2cov_nan", "fro_2cov_reg", "k74", "k105"):
+        c = load_case(name)
+        fused = make_engine(c, x_dtype="x3")
+        fused.run(c.T, with_loss=True)
+        a = (fused.get_factors(), fused.losses())
+        fused.close()
+        monkeypatch.setenv(knob, "0" if knob == "ALPINE_HIP_FUSED_W" else "1")
+        sep = make_engine(c, x_dtype="x3")
+        monkeypatch.delenv(knob)
+        sep.run(c.T, with_loss=True)
+        b = (sep.get_factors(), sep.losses())
+        sep.close()
+        assert rel_fro(a[0][0], b[0][0]) < 2e-5 and rel_fro(a[0][1], b[0][1]) < 2e-5
+        assert_loss_rows_close(a[1], b[1], n_cells=c.X.shape[0], rtol=2e-5)
+
+
+def test_fit_uploads_X_once_and_keeps_it_for_compute_loss_and_transform(monkeypatch):
+    """fit(max_iter=None) = 200-iteration warm-up + final run on ONE resident copy of X; compute_loss(adata) / transform(adata)
+    on the fitted adata reuse that copy (no upload) and agree with a model that re-uploads."""
+    from alpine_amd import ALPINE, MiniAnnData
+    nat = _native()
+    c = load_case("kl_2cov_nan")
+    uploads = []
+    real = nat.NativeShard.upload_X_host
+
+    def counting(self, X, *a, **kw):
+        uploads.append(X.shape)
+        return real(self, X, *a, **kw)
+    monkeypatch.setattr(nat.NativeShard, "upload_X_host", counting)
+    ad = MiniAnnData(c.X.copy(), c.obs.copy())
+    m = ALPINE(device="cuda:0", **c.params).fit(ad, covariate_keys=c.keys, max_iter=None)
+    n_fit = len(uploads)
+    assert n_fit == 1 and len(m.loss_history) == m.max_iter           # one chunk, one upload -- warm-up included
+    loss = m.compute_loss(ad)
+    emb = np.array(ad.obsm["ALPINE_embedding"])
+    m._advance_rng_like_reference_fit()                                # the lazy replay of the fit's randperm draws happens now
+    torch_state = __import__("torch").get_rng_state()
+    m.transform(ad, n_iter=10)
+    assert len(uploads) == n_fit                                       # both served from the resident engine
+    Ht = np.array(ad.obsm["ALPINE_embedding"])
+    # the same calls on a model that does not keep its engine
+    ad2 = MiniAnnData(c.X.copy(), c.obs.copy())
+    m2 = ALPINE(device="cuda:0", keep_resident=False, **c.params).fit(ad2, covariate_keys=c.keys, max_iter=m.max_iter)
+    assert m2._resident is None and np.array_equal(np.array(ad2.obsm["ALPINE_embedding"]), emb)
+    n2 = len(uploads)
+    loss2 = m2.compute_loss(ad2)
+    __import__("torch").set_rng_state(torch_state)
+    m2._rng_replay = None
+    m2.transform(ad2, n_iter=10)
+    assert len(uploads) == n2 + 2                                      # compute_loss and transform each re-upload
+    assert abs(loss - loss2) <= 1e-6 * abs(loss2)
+    assert rel_fro(Ht, np.array(ad2.obsm["ALPINE_embedding"])) < 1e-6
+    # a different matrix (or an edited one) is never served from the resident copy
+    ad3 = MiniAnnData(c.X.copy(), c.obs.copy())
+    before = len(uploads)
+    m.transform(ad3, n_iter=2)
+    assert len(uploads) == before + 1
+    m.release()
+    assert m._resident is None

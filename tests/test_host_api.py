@@ -190,6 +190,35 @@ def test_fit_rejects_non_anndata_and_unsupported_modes():
         ALPINE(n_components=3, n_covariate_components=[2], lam=[]).fit(a, covariate_keys=["c"], max_iter=1)
 
 
+def test_build_limits_are_reported_from_python_before_any_device_work():
+    """Limits of the MI355X build that the reference does not have (Deviations): a clear Python-side
+    NotImplementedError instead of a late native status."""
+    from alpine_amd import ALPINE
+    a = _adata()
+    a.obs["d"] = a.obs["c"].copy()
+    with pytest.raises(NotImplementedError, match="entries of 0"):
+        ALPINE(n_components=3, n_covariate_components=[0], lam=[1.0]).fit(a, covariate_keys=["c"], max_iter=1)
+    with pytest.raises(NotImplementedError, match="first 64 columns"):
+        ALPINE(n_components=3, n_covariate_components=[40, 30], lam=[1.0, 1.0]).fit(a, covariate_keys=["c", "d"], max_iter=1)
+    with pytest.raises(NotImplementedError, match="> 128"):
+        ALPINE(n_components=127, n_covariate_components=[2], lam=[1.0]).fit(a, covariate_keys=["c"], max_iter=1)
+    with pytest.raises(ValueError, match="shard_comm must be"):
+        ALPINE(shard_comm="mpi", **GOOD)
+    with pytest.raises(TypeError, match="keep_resident must be a boolean"):
+        ALPINE(keep_resident=1, **GOOD)
+
+
+def test_shard_bounds_and_empty_shards():
+    from alpine_amd.sharded import check_shardable, shard_bounds
+    for n, w in [(200000, 8), (1000, 3), (257, 2), (64, 8)]:
+        cuts = [shard_bounds(n, w, r) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert all(c0 % 8 == 0 for c0, _ in cuts)
+        check_shardable(n, w)
+    with pytest.raises(ValueError, match="would hold no cells"):
+        check_shardable(10, 4)            # interior cuts round to multiples of 8: rank 0 would get [0, 0)
+
+
 def test_synthetic_generator_is_count_like():
     from alpine_amd.datasets import synth_counts_host, synth_labels_host
     X = synth_counts_host(300, 200, rank=8, seed=1)
