@@ -937,12 +937,14 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
     } else {
         HTail tail{};
         const int hblocks = (int)((v.N + 127) / 128);
+        tail.ybuf_rows = (c->nYrows > 0 && c->nYrows <= HT_YROWS_MAX) ? c->nYrows : 0;      // Y of a block's cells in LDS
+        h_bytes_mfma += sizeof(float) * (size_t)tail.ybuf_rows * HS_CELLS;
         if (with_tail) {
             int max_k, max_ct;
             cov_maxima(c, &max_k, &max_ct);
             tail.gram_part = c->gramPartH; tail.stat_part = c->statPartH;
             tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
-            h_bytes_mfma += 2 * hstats_group_bytes(max_k, max_ct);
+            h_bytes_mfma += tail.ybuf_rows ? hstats_tail_bytes(max_k, max_ct) : 2 * hstats_group_bytes(max_k, max_ct);
         }
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
                                                c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov, tail));

@@ -1076,10 +1076,89 @@ __device__ __forceinline__ void gram_of_lds_tiles(const float* __restrict__ tral
     }
 }
 
+// Covariate statistics of one 128-cell group inside the fused H update (same quantities and the same per-(class, component)
+// arithmetic as hstats_group): the updated H rows come from the waves' LDS tiles, Y from the block's LDS copy, B from the
+// block's LDS copy -- no global load on the way, 2-3 barriers per covariate.  256 threads: threads 0..127 own one cell each
+// for the per-cell part, all four waves share the reductions over cells.
+//   smem: double lred[4]; float hbuf[max_k][128]; float zbuf[max_ct][128]
+constexpr int HT_YROWS_MAX = 32;      // rows of Y (sum of the covariates' levels) that the block keeps in LDS (16 KB)
+
+__host__ __device__ inline size_t hstats_tail_bytes(int max_k, int max_ct)
+{
+    return (sizeof(double) * 4 + sizeof(float) * (size_t)(max_k + max_ct) * HS_CELLS + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ void hstats_tail(const float* __restrict__ trall, int LD, int TRSZ, const float* __restrict__ ybuf,
+                                            const float* __restrict__ Bl, const CovMeta& meta, float* __restrict__ out,
+                                            int64_t cell0, int N, float eps, int max_k, int max_ct, unsigned char* __restrict__ smem)
+{
+    double* lred = reinterpret_cast<double*>(smem);
+    float (*hbuf)[HS_CELLS] = reinterpret_cast<float (*)[HS_CELLS]>(lred + 4);
+    float (*zbuf)[HS_CELLS] = hbuf + max_k;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool cellthread = tid < HS_CELLS;
+    const bool valid = cellthread && cell0 + tid < N;
+    const float* hrow = trall + (tid >> 5 & 3) * TRSZ + (tid & 31) * LD;
+    for (int i = 0; i < meta.n_cov; ++i) {
+        const int ki = meta.k[i], Ci = meta.lev[i], off = meta.off[i], bo = meta.boff[i];
+        const float lam = meta.lam[i];
+        float* so = out + meta.soff[i];
+        __syncthreads();                                       // the previous covariate's readers are done with hbuf / zbuf
+        if (cellthread)
+            for (int k = 0; k < ki; ++k) hbuf[k][tid] = valid ? hrow[off + k] : 0.f;
+        double lacc = 0.0;
+        for (int c0 = 0; c0 < Ci; c0 += max_ct) {
+            const int ct = min(max_ct, Ci - c0);
+            if (c0 > 0) __syncthreads();                       // zbuf is reused by the next chunk of classes
+            if (cellthread) {
+                for (int c = 0; c < ct; ++c) {
+                    float bh = 0.f;
+                    for (int k = 0; k < ki; ++k) bh = fmaf(Bl[bo + (c0 + c) * ki + k], hbuf[k][tid], bh);
+                    const float y = valid ? ybuf[(meta.yoff[i] + c0 + c) * HS_CELLS + tid] : 0.f;
+                    float z;
+                    if (meta.loss_type == 0) {
+                        const float yh = fmaxf(bh, eps);
+                        z = lam * (y / yh);
+                        if (valid) lacc += (double)(y * logf(fmaxf(y / yh, eps)) - y + yh);
+                    } else {
+                        z = y;
+                        const float d = y - bh;
+                        if (valid) lacc += (double)(d * d);
+                    }
+                    zbuf[c][tid] = valid ? z : 0.f;
+                }
+            }
+            __syncthreads();
+            for (int p = wave; p < ct * ki; p += 4) {
+                const int c = p / ki, k = p % ki;
+                float v = zbuf[c][lane] * hbuf[k][lane];
+                v = fmaf(zbuf[c][lane + 64], hbuf[k][lane + 64], v);
+                v = wave_sum_f32(v);
+                if (lane == 0) so[(c0 + c) * ki + k] = v;
+            }
+        }
+        for (int k = wave; k < ki; k += 4) {
+            float v = lam * hbuf[k][lane] + lam * hbuf[k][lane + 64];
+            v = wave_sum_f32(v);
+            if (lane == 0) so[Ci * ki + k] = v;
+        }
+        const double ws = wave_sum_f64(lacc);                  // waves 2, 3 hold zeros
+        if (lane == 0) lred[wave] = ws;
+        __syncthreads();
+        if (tid == 0) {
+            const double tot = lred[0] + lred[1];
+            const float hi = (float)tot;
+            so[Ci * ki + ki] = hi;
+            so[Ci * ki + ki + 1] = (float)(tot - (double)hi);
+        }
+    }
+}
+
 struct HTail {
     float* gram_part;       // [gridDim.x][KP*KP], nullptr = no tail
     float* stat_part;       // [groups][nstat]
     int nstat, max_k, max_ct;
+    int ybuf_rows;          // rows of Y the block copies into LDS (all of them when they fit HT_YROWS_MAX, else 0 = read Y from global)
 };
 
 template <int KT>
@@ -1101,9 +1180,20 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     const int c = lane & 31, h = lane >> 5;
     float* trall = smem + KP * KP + ((nB + 3) & ~3);                 // 4 x [32][KP + 4]: the waves' tiles of one 128-cell group
     float* tr = trall + wave * TRSZ;
-    unsigned char* hs_smem = reinterpret_cast<unsigned char*>(trall + 4 * TRSZ);   // tail only: 2 x hstats_group_bytes
+    float* ybuf = trall + 4 * TRSZ;                                                 // [ybuf_rows][128]: Y of the block's cells
+    unsigned char* hs_smem = reinterpret_cast<unsigned char*>(ybuf + tail.ybuf_rows * HS_CELLS);   // tail only: statistics scratch
     const bool with_tail = tail.gram_part != nullptr;
-    for (int idx = tid; idx < KP * KP; idx += 256) M2l[idx] = 2.f * WtW[idx];
+    const bool y_lds = tail.ybuf_rows > 0;
+    {
+        // Y of this block's 128 cells: one load phase up front instead of a dependent global load per (covariate, class)
+        const int64_t cell0 = (int64_t)blockIdx.x * HS_CELLS;
+        for (int idx = tid; idx < tail.ybuf_rows * HS_CELLS; idx += 256) {
+            const int row = idx >> 7, t = idx & (HS_CELLS - 1);
+            ybuf[idx] = cell0 + t < N ? Y[(int64_t)row * Np + cell0 + t] : 0.f;
+        }
+    }
+    for (int idx = tid; idx < KP * KP / 4; idx += 256)
+        reinterpret_cast<f32x4*>(M2l)[idx] = 2.f * reinterpret_cast<const f32x4*>(WtW)[idx];
     for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];
     __syncthreads();
 
@@ -1167,7 +1257,8 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                                 part = fmaf(coef, hreg[m][q][e], part);
                             }
                     const float bh = part + __shfl_xor(part, 32, 64);
-                    const float y = valid ? Y[(int64_t)(meta.yoff[i] + cl) * Np + n] : 0.f;
+                    const float y = y_lds ? ybuf[(meta.yoff[i] + cl) * HS_CELLS + wave * 32 + c]
+                                          : (valid ? Y[(int64_t)(meta.yoff[i] + cl) * Np + n] : 0.f);
                     const float z = (meta.loss_type == 0) ? y / fmaxf(bh, eps) : y;
 #pragma unroll
                     for (int m = 0; m < GT; ++m)
@@ -1207,12 +1298,16 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
         __syncthreads();                                                       // the four tiles of this group are in LDS
         gram_of_lds_tiles<KT>(trall, wave, lane, tail.gram_part + (int64_t)blockIdx.x * KP * KP);      // H H^T over the block's 128 cells
         if (meta.n_cov > 0) {
-            // covariate statistics of this 128-cell group; threads 128..255 walk the same barriers on the same cells with
-            // their own scratch slice and write the same values (as phase1_open_kernel's odd last group does)
-            const int t7 = tid & (HS_CELLS - 1);
-            const float* hr = trall + (t7 >> 5) * TRSZ + (t7 & 31) * LD;
-            hstats_group([hr](int k) { return hr[k]; }, Y, B, meta, tail.stat_part, N, Np, eps, tail.nstat, tail.max_k, tail.max_ct,
-                         hs_smem, tid >> 7, grp);
+            if (y_lds) {
+                hstats_tail(trall, LD, TRSZ, ybuf, Bl, meta, tail.stat_part + grp * tail.nstat, grp * HS_CELLS, N, eps, tail.max_k, tail.max_ct, hs_smem);
+            } else {
+                // many label levels: the stand-alone arithmetic with Y from global memory; threads 128..255 walk the same
+                // barriers on the same cells with their own scratch slice and write the same values
+                const int t7 = tid & (HS_CELLS - 1);
+                const float* hr = trall + (t7 >> 5) * TRSZ + (t7 & 31) * LD;
+                hstats_group([hr](int k) { return hr[k]; }, Y, B, meta, tail.stat_part, N, Np, eps, tail.nstat, tail.max_k, tail.max_ct,
+                             hs_smem, tid >> 7, grp);
+            }
         }
     }
 }
