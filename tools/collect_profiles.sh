@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything that goes under profiles/rNN/, in one gpurun call (run from the repo root; ~15 GPU-minutes):
+#   bash tools/collect_profiles.sh          -> gpurun_out/prof/*
+# cfg3 in every sweep mode with PMC passes (the headline + BASELINE config 5 + the full-significand leg), then kernel traces
+# and per-iteration timelines of the other shapes: one of 8 shards of cfg3 (25 000 cells), cfg2, cfg4's per-GPU share
+# (125 000 cells, K = 105) in x3 and f32, and the default bench line.
+set -e
+export TIMELINE_ANCHOR=w_update_mfma
+bash tools/profile_mode.sh x3 cfg3
+bash tools/profile_mode.sh x3 cfg3 fullsig --x-scale 0.3712345
+bash tools/profile_mode.sh f32 cfg3
+bash tools/profile_mode.sh split cfg3
+bash tools/profile_mode.sh bf16 cfg3
+export STATS_ONLY=1
+bash tools/profile_mode.sh x3 cfg3 shard8 --cells 25000
+bash tools/profile_mode.sh x3 cfg2
+bash tools/profile_mode.sh f32 cfg2
+bash tools/profile_mode.sh x3 cfg4 share8 --cells 125000
+bash tools/profile_mode.sh x3 cfg4 share8_fullsig --cells 125000 --x-scale 0.3712345
+bash tools/profile_mode.sh f32 cfg4 share8 --cells 125000
+unset STATS_ONLY TIMELINE_ANCHOR
+python3 bench.py > gpurun_out/prof/bench_default_cfg3.json 2> gpurun_out/prof/bench_default_cfg3.err
+echo "collect_profiles done"
