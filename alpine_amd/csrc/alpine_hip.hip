@@ -772,12 +772,17 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         SweepGeom gx = g;
         if (c->ablate_flush) gx.panel_fixed = 2;
         if (c->x3_wide && !c->x3_ablate) {
+            const bool pad_tile = c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
+#define X3W_LAUNCH(KT_, NH_) do { \
+                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
+                else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
             switch (c->KT) {
-                case 1: hipLaunchKernelGGL((stream_gemm_x3w_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
-                case 2: hipLaunchKernelGGL((stream_gemm_x3w_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
-                case 3: hipLaunchKernelGGL((stream_gemm_x3w_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
-                default: hipLaunchKernelGGL((stream_gemm_x3w_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+                case 1: X3W_LAUNCH(1, 2); break;
+                case 2: X3W_LAUNCH(2, 2); break;
+                case 3: X3W_LAUNCH(3, 1); break;
+                default: X3W_LAUNCH(4, 1); break;
             }
+#undef X3W_LAUNCH
             HIPCHK(c, hipGetLastError());
             return 0;
         }

@@ -320,12 +320,16 @@ __device__ __forceinline__ void sg_flush_tile16(float* __restrict__ tr, const f3
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int KT, int NH>
+// M16A = 16-component tiles that hold real components (ceil(K / 16) <= 2 KT): the padding tile of a model with
+// K <= 32 KT - 16 (K = 105 -> 7 of 8 tiles) is never multiplied -- its accumulators stay zero and are flushed as zeros, so the
+// pieces keep their [.][KP] layout and every consumer is unchanged.  12.5 % fewer MFMAs at K = 105.
+template <int KT, int NH, int M16A = 2 * KT>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
                             int64_t ldS, SweepGeom g)
 {
     static_assert(KT * NH <= 4, "256 accumulator registers per lane");
+    static_assert(M16A == 2 * KT || M16A == 2 * KT - 1, "at most one padding tile");
     constexpr int KP = 32 * KT, M16 = 2 * KT;
     constexpr int WAVE_F = 128 * NH, BLOCK_F = 4 * WAVE_F, NCG = 2 * NH;       // 64-column groups per wave
     constexpr int NT = 256;
@@ -431,11 +435,11 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
         // one stage: A fragments of the three panel planes, then per 64-column group: 4 x (split one tile's 8 float32 into
         // planes, 6 * M16 MFMAs), then the group's 8 loads are re-issued for the next stage
         auto stage = [&](const unsigned short* __restrict__ lrow, int t_next, bool last) {
-            u32x4 a[3][M16];
+            u32x4 a[3][M16A];
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
-                for (int m = 0; m < M16; ++m)
+                for (int m = 0; m < M16A; ++m)
                     a[pp][m] = *reinterpret_cast<const u32x4*>(lrow + pp * STAGE_BF16 + (16 * m) * 8);
 #pragma unroll
             for (int cg = 0; cg < NCG; ++cg) {
@@ -449,7 +453,7 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
 #pragma unroll
                     for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
-                        for (int m = 0; m < M16; ++m)
+                        for (int m = 0; m < M16A; ++m)
                             acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
                                                                                          __builtin_bit_cast(bf16x8, b[0]), acc[m][4 * cg + t], 0, 0, 0);
                     // mid / lo planes of X: nothing to add when the whole 32 x 16 tile is exactly one bf16 plane (wave-uniform test)
@@ -458,11 +462,11 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
 #pragma unroll
                         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                            for (int m = 0; m < M16; ++m)
+                            for (int m = 0; m < M16A; ++m)
                                 acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
                                                                                              __builtin_bit_cast(bf16x8, b[1]), acc[m][4 * cg + t], 0, 0, 0);
 #pragma unroll
-                        for (int m = 0; m < M16; ++m)
+                        for (int m = 0; m < M16A; ++m)
                             acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]),
                                                                                          __builtin_bit_cast(bf16x8, b[2]), acc[m][4 * cg + t], 0, 0, 0);
                     }

@@ -265,6 +265,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_workers(args))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # before the HIP runtime starts: the host driver only supports dmabuf IPC
     import torch
     import torch.distributed as dist
     from alpine_amd import _native

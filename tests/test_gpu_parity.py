@@ -809,3 +809,32 @@ def test_fit_uploads_X_once_and_keeps_it_for_compute_loss_and_transform(monkeypa
     assert len(uploads) == before + 1
     m.release()
     assert m._resident is None
+
+
+def test_trace_form_loss_cancellation_bound_on_a_near_exact_fit():
+    """The per-iteration reconstruction loss is the trace form ||X||^2 - 2<XH^T, W> + <W^TW, HH^T> built from float32 sweep
+    results (finalised in float64).  When the fit is nearly exact (recon << ||X||^2) the three terms cancel and the ABSOLUTE
+    error stays at the float32 level of ||X||^2 -- i.e. the relative error of the small difference grows like
+    ||X||^2 / recon.  DESIGN.md 2 states the bound |trace - direct| <= 1e-6 ||X||^2; this pins it on X = WH (1 + 1e-3 noise)."""
+    nat = _native()
+    rng = np.random.default_rng(7)
+    G, N, K = 300, 700, 12
+    W = rng.uniform(0.1, 1.0, size=(G, K)).astype(np.float32)
+    H = rng.uniform(0.1, 1.0, size=(K, N)).astype(np.float32)
+    X = ((W @ H).T * (1.0 + 1e-3 * rng.standard_normal((N, G)))).clip(min=0).astype(np.float32)
+    Y = np.zeros((2, N), dtype=np.float32)
+    Y[rng.integers(0, 2, size=N), np.arange(N)] = 1.0
+    B = rng.uniform(0.1, 1.0, size=(2, 2)).astype(np.float32)
+    for x_dtype in ("x3", "f32"):
+        eng = nat.NativeShard(n_genes=G, n_cells=N, n_components=K - 2, cov_components=[2], cov_levels=[2], lam=[1.0], x_dtype=x_dtype)
+        eng.upload_X_host(X)
+        eng.finalize_X()
+        eng.upload_Y(0, Y)
+        eng.set_factors(W, H, [B])
+        eng.epoch_loss()                           # loss row of the CURRENT factors, trace form
+        trace = eng.losses()[-1, 1]
+        direct = eng.eval_recon_direct()           # float64 direct form on the same factors
+        xn = eng.info().x_sqnorm
+        eng.close()
+        assert direct < 5e-6 * xn                  # the fit really is near exact: recon / ||X||^2 ~ 1e-6
+        assert abs(trace - direct) <= 1e-6 * xn, (x_dtype, trace, direct, xn)
