@@ -614,7 +614,10 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         double multi = 0;
         for (int b = 0; b < blocks; ++b) multi += h[(size_t)blocks + b];
         c->x_multi_plane_frac = multi / ((double)c->G * (double)c->N);
-        c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && c->x_multi_plane_frac > 0.01);
+        // (wide models with an all-padding 16-component tile -- K = 105 -> 7 of 8 tiles -- are matrix-pipe-bound in both data
+        // regimes and x3w never multiplies that tile: 11 % faster on full significands, 5 % on counts at K = 105)
+        const bool pad_tile = c->K <= c->KP - 16;
+        c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3)));
     }
     c->x_final = true;
     return 0;
