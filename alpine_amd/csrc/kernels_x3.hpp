@@ -323,10 +323,9 @@ __device__ __forceinline__ void sg_flush_tile16(float* __restrict__ tr, const f3
 // M16A = 16-component tiles that hold real components (ceil(K / 16) <= 2 KT): the padding tile of a model with
 // K <= 32 KT - 16 (K = 105 -> 7 of 8 tiles) is never multiplied -- its accumulators stay zero and are flushed as zeros, so the
 // pieces keep their [.][KP] layout and every consumer is unchanged.  12.5 % fewer MFMAs at K = 105.
-// SKIP = test every 32 x 16 tile of X for an all-zero mid plane and skip its mid / lo products (count-like data).  On data
-// with full significands the test always fails; without it a 64-column group is ONE basic block (4 splits + 96 MFMAs at
-// K <= 64) that the scheduler can interleave freely.
-template <int KT, int NH, int M16A = 2 * KT, bool SKIP = true>
+// (A variant WITHOUT the zero-plane test -- on full significands it always fails, and without the branch a 64-column group
+// is one basic block for the scheduler -- was 3 % slower in A/B, cfg3 and K = 105: the test stays.)
+template <int KT, int NH, int M16A = 2 * KT>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
                             int64_t ldS, SweepGeom g)
@@ -461,7 +460,7 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
                                                                                          __builtin_bit_cast(bf16x8, b[0]), acc[m][4 * cg + t], 0, 0, 0);
                     // mid / lo planes of X: nothing to add when the whole 32 x 16 tile is exactly one bf16 plane (wave-uniform test)
                     const unsigned rest = (b[1][0] | b[1][1] | b[1][2] | b[1][3]) & 0x7fff7fffu;
-                    if (!SKIP || __builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
+                    if (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
 #pragma unroll
                         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
