@@ -98,8 +98,9 @@ def test_reduce_block_matches_numpy(name):
     eng.close()
 
 
-# x_dtype "x3": float32 X, every product formed from exact bf16 planes on the bf16 matrix pipe (kernels_x3.hpp; takes
-# effect for K <= 64, wider cases run the float32 MFMA) -- held to the SAME tolerances against the reference.
+# x_dtype "x3": float32 X, every product formed from exact bf16 planes on the bf16 matrix pipe (kernels_x3.hpp; every K <= 128:
+# the gamma-distributed cases take the 16x16x32 form "x3w", the count cases the 32x32x16 form -- chosen from the data) --
+# held to the SAME tolerances against the reference.
 @pytest.mark.parametrize("x_dtype", ["f32", "x3"])
 @pytest.mark.parametrize("name", SMALL_CASES)
 def test_single_step_vs_reference(name, x_dtype):
