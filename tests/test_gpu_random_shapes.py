@@ -122,3 +122,43 @@ def test_random_shape_als_and_minibatch_vs_oracle(seed):
             assert rel_fro(b, bo.numpy()) < 1e-4, tag
         want = np.array(s.losses)
         np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=1e-4, err_msg=tag)
+
+
+@pytest.mark.parametrize("loss_type", ["kl-divergence", "frobenius"])
+def test_many_label_levels_vs_oracle(loss_type):
+    """More label levels than the H update keeps in LDS (sum of levels = 43 > 32): the fused tail then takes the stand-alone
+    statistics arithmetic with Y from global memory, and the guided terms read Y from global memory too.  Five MU steps, so
+    the tail's output feeds four phase 1s and the closing loss row."""
+    from alpine_amd import _native as nat
+    rng = np.random.default_rng(11)
+    G, N = 150, 700
+    levels, ks = [40, 3], [4, 2]
+    X = rng.gamma(0.5, 2.0, size=(N, G)).astype(np.float32)
+    Ys = []
+    for C in levels:
+        lab = rng.integers(0, C, size=N)
+        Y = np.zeros((N, C), dtype=np.float32)
+        Y[np.arange(N), lab] = 1.0
+        Ys.append(Y)
+    p = orc.OracleParams(n_components=9, n_covariate_components=ks, lam=[50.0, 1e3], orth_W=0.1, alpha_W=0.5, l1_ratio_W=0.3,
+                         loss_type=loss_type, random_state=5)
+    s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
+    W0, H0, B0 = s.W.numpy().copy(), s.H.numpy().copy(), [b.numpy().copy() for b in s.Bs]
+    orc.fit_fused(p, s, 5, with_loss=True)
+    eng = nat.NativeShard(n_genes=G, n_cells=N, n_components=p.n_components, cov_components=ks, cov_levels=levels, lam=p.lam,
+                          orth_W=p.orth_W, alpha_W=p.alpha_W, l1_ratio_W=p.l1_ratio_W, eps=p.eps, loss_type=loss_type, x_dtype="x3")
+    eng.upload_X_host(X)
+    eng.finalize_X()
+    for i, y in enumerate(Ys):
+        eng.upload_Y(i, np.ascontiguousarray(y.T))
+    eng.set_factors(W0, H0, B0)
+    eng.run(5, with_loss=True)
+    W, H, Bs = eng.get_factors()
+    losses = eng.losses()
+    eng.close()
+    assert rel_fro(W, s.W.numpy()) < 5e-5 and rel_fro(H, s.H.numpy()) < 5e-5
+    for b, bo in zip(Bs, s.Bs):
+        assert rel_fro(b, bo.numpy()) < 1e-4
+    want = np.array(s.losses)
+    np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=1e-4)
+    np.testing.assert_allclose(losses[:, 2:], want[:, 2:], rtol=2e-3, atol=1e-6 * N)
