@@ -617,7 +617,7 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         // (wide models with an all-padding 16-component tile -- K = 105 -> 7 of 8 tiles -- are matrix-pipe-bound in both data
         // regimes and x3w never multiplies that tile: 11 % faster on full significands, 5 % on counts at K = 105)
         const bool pad_tile = c->K <= c->KP - 16;
-        c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3)));
+        c->x3_wide = c->x3_variant == 2 || c->x3_variant == 6 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3)));
     }
     c->x_final = true;
     return 0;
@@ -777,7 +777,9 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         if (c->x3_wide && !c->x3_ablate) {
             const bool pad_tile = c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
 #define X3W_LAUNCH(KT_, NH_) do { \
-                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
+                if (c->x3_variant == 6 && pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1, true>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
+                else if (c->x3_variant == 6) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_, true>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
+                else if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
             switch (c->KT) {
                 case 1: X3W_LAUNCH(1, 2); break;

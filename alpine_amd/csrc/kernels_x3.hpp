@@ -396,7 +396,9 @@ __device__ __forceinline__ void sg_flush_tile16(float* __restrict__ tr, const f3
 // pieces keep their [.][KP] layout and every consumer is unchanged.  12.5 % fewer MFMAs at K = 105.
 // (A variant WITHOUT the zero-plane test -- on full significands it always fails, and without the branch a 64-column group
 // is one basic block for the scheduler -- was 3 % slower in A/B, cfg3 and K = 105: the test stays.)
-template <int KT, int NH, int M16A = 2 * KT>
+// PIN: the split written stage-wise and the issue order pinned with sched_group_barrier -- one 16-cycle MFMA, then 2-3 of the
+// split's VALU ops -- instead of the compiler's own interleave.
+template <int KT, int NH, int M16A = 2 * KT, bool PIN = false>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
                             int64_t ldS, SweepGeom g)
@@ -521,6 +523,62 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = x[cg][e][t];
+                    if constexpr (PIN) {
+                        u32x4 b0, b1, b2;
+                        float r[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b0[q] = x3_cvt2(v[2 * q], v[2 * q + 1]);
+                        // ---- block 1: 3 M16A hi products || unpack(hi), r = x - hi, mid = cvt(r), zero test
+#pragma unroll
+                        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                            for (int m = 0; m < M16A; ++m)
+                                acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
+                                                                                             __builtin_bit_cast(bf16x8, b0), acc[m][4 * cg + t], 0, 0, 0);
+                        float hs[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { hs[2 * q] = __uint_as_float(b0[q] << 16); hs[2 * q + 1] = __uint_as_float(b0[q] & 0xffff0000u); }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) r[e] = v[e] - hs[e];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b1[q] = x3_cvt2(r[2 * q], r[2 * q + 1]);
+                        const unsigned restp = (b1[0] | b1[1] | b1[2] | b1[3]) & 0x7fff7fffu;
+                        __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+#pragma unroll
+                        for (int i = 0; i < 3 * M16A - 1; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, (23 + 3 * M16A - 2) / (3 * M16A - 1), 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        if (__builtin_amdgcn_ballot_w64(restp != 0u) != 0ull) {
+                            // ---- block 2: 2 M16A mid products, M16A lo products || unpack(mid), s = r - mid, lo = cvt(s)
+#pragma unroll
+                            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                                for (int m = 0; m < M16A; ++m)
+                                    acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
+                                                                                                 __builtin_bit_cast(bf16x8, b1), acc[m][4 * cg + t], 0, 0, 0);
+                            float ms[8], sres[8];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { ms[2 * q] = __uint_as_float(b1[q] << 16); ms[2 * q + 1] = __uint_as_float(b1[q] & 0xffff0000u); }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sres[e] = r[e] - ms[e];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) b2[q] = x3_cvt2(sres[2 * q], sres[2 * q + 1]);
+#pragma unroll
+                            for (int m = 0; m < M16A; ++m)
+                                acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]),
+                                                                                             __builtin_bit_cast(bf16x8, b2), acc[m][4 * cg + t], 0, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < 2 * M16A; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x2, (20 + 2 * M16A - 1) / (2 * M16A), 0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < M16A; ++i) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        }
+                        continue;
+                    }
                     u32x4 b[3];
                     x3_split8_scalar(v, b);
 #pragma unroll
