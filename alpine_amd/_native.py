@@ -325,8 +325,9 @@ class NativeShard:
         self._chk(self._lib.alpine_eval_recon_direct(self._h, C.byref(out)))
         return out.value
 
-    def set_profiling(self, on: bool):
-        self._chk(self._lib.alpine_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on):
+        """False / 0 = off, True / 1 = events around every sweep and all-reduce, n > 1 = every n-th iteration only."""
+        self._chk(self._lib.alpine_set_profiling(self._h, int(on)))
 
     def kernel_time(self, which: int):
         ms, n = C.c_double(), C.c_int64()

@@ -119,6 +119,9 @@ struct alpine_ctx {
     double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
     // profiling
     bool prof = false;
+    int prof_every = 1;               // events bracket the launches of every prof_every-th phase 1 / iteration only
+    int64_t prof_tick = 0;            // phase-1 counter; prof_now = prof && prof_tick % prof_every == 0
+    bool prof_now = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ALPINE_KERNEL_COUNT];
     size_t ev_used[ALPINE_KERNEL_COUNT] = {};
 };
@@ -617,7 +620,7 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         // (wide models with an all-padding 16-component tile -- K = 105 -> 7 of 8 tiles -- are matrix-pipe-bound in both data
         // regimes and x3w never multiplies that tile: 11 % faster on full significands, 5 % on counts at K = 105)
         const bool pad_tile = c->K <= c->KP - 16;
-        c->x3_wide = c->x3_variant == 2 || c->x3_variant == 6 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3)));
+        c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3)));
     }
     c->x_final = true;
     return 0;
@@ -702,7 +705,7 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
 // ---------------------------------------------------------------------------------- iteration
 static int prof_begin(alpine_ctx* c, int which)
 {
-    if (!c->prof) return 0;
+    if (!c->prof_now) return 0;
     auto& v = c->ev[which];
     if (c->ev_used[which] == v.size()) {
         hipEvent_t a, b;
@@ -715,7 +718,7 @@ static int prof_begin(alpine_ctx* c, int which)
 }
 static int prof_end(alpine_ctx* c, int which)
 {
-    if (!c->prof) return 0;
+    if (!c->prof_now) return 0;
     HIPCHK(c, hipEventRecord(c->ev[which][c->ev_used[which]].second, c->stream));
     c->ev_used[which]++;
     return 0;
@@ -777,9 +780,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         if (c->x3_wide && !c->x3_ablate) {
             const bool pad_tile = c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
 #define X3W_LAUNCH(KT_, NH_) do { \
-                if (c->x3_variant == 6 && pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1, true>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
-                else if (c->x3_variant == 6) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_, true>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
-                else if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
+                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
             switch (c->KT) {
                 case 1: X3W_LAUNCH(1, 2); break;
@@ -799,8 +800,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
                 if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
 #endif
-                if (c->x3_variant == 5) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 5>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
             default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
@@ -843,6 +843,7 @@ static int ready(alpine_ctx* c)
 static int phase1(alpine_ctx* c, const CellView& v)
 {
     int rc;
+    c->prof_now = c->prof && (c->prof_tick++ % c->prof_every) == 0;      // holds until the next phase 1 (covers the all-reduce and the W^TX sweep)
     const int KP = c->KP;
     int max_k = 1, max_c = 1;
     for (int i = 0; i < c->n_cov; ++i) { max_k = std::max(max_k, c->cov_k[i]); max_c = std::max(max_c, c->cov_lev[i]); }
@@ -1467,7 +1468,12 @@ extern "C" int alpine_eval_recon_direct(alpine_ctx* c, double* out)
 extern "C" int alpine_set_profiling(alpine_ctx* c, int enabled)
 {
     if (!c) return ALPINE_ERR_BAD_ARG;
+    // enabled = n > 0: events around the sweeps / all-reduce of every n-th iteration (1 = every launch).  An event record
+    // between two kernels costs the stream ~2 us: sampling keeps the measurement from slowing sub-millisecond iterations
     c->prof = enabled != 0;
+    c->prof_every = enabled > 1 ? enabled : 1;
+    c->prof_tick = 0;
+    c->prof_now = c->prof;
     for (int k = 0; k < ALPINE_KERNEL_COUNT; ++k) c->ev_used[k] = 0;
     return 0;
 }

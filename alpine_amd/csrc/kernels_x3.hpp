@@ -50,7 +50,9 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 (&b)[3])
 // The same split written on scalars (used by the 16x16x32 form below): no float2 temporaries, so the compiler neither needs
 // register pairs (v_mov copies) nor forms v_pk_add_f32; 11 single-issue VALU ops per pair of values.  Same values as x3_split8.
 // (A/B on the 32x32x16 kernel, together with sched_group_barrier interleaves of the split between the MFMAs: 0.4 - 2 %
-// SLOWER than the compiler's own schedule of the float2 form, so that kernel keeps x3_split8.)
+// SLOWER than the compiler's own schedule of the float2 form, so that kernel keeps x3_split8.  A second attempt -- the split
+// written stage-wise, one tile ahead, "1 MFMA : 5 VALU" pinned -- was 3 % faster on full significands, 2.5 % slower on counts;
+// the 16x16x32 form below is faster than either on full significands, and pinning ITS schedule loses 4 %: DESIGN.md 4.2c.)
 __device__ __forceinline__ unsigned x3_cvt2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bf16x2v)); }
 __device__ __forceinline__ void x3_split8_scalar(const float (&v)[8], u32x4 (&b)[3])
 {
@@ -92,77 +94,6 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
         }
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
-            if constexpr (ABL == 5) {
-                // Software-pipelined form: the split is written STAGE-wise (4 pairs side by side: every op of a stage is
-                // independent of the others of that stage) and one tile ahead -- the hi plane of tile t+1 is converted while
-                // tile t's hi products issue -- and sched_group_barrier pins "1 MFMA, then 4-5 VALU ops" so that every MFMA gap
-                // carries independent vector work and no gap carries more than hides beside a 32-cycle MFMA.
-                unsigned hi_next[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hi_next[q] = x3_cvt2(x[p][hf][2 * q][0], x[p][hf][2 * q + 1][0]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = x[p][hf][e][t];
-                    u32x4 b0, b1, b2;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b0[q] = hi_next[q];
-                    float r[8];
-                    // ---- block 1: 3 KT hi products || unpack(hi), r = x - hi, mid = cvt(r), hi of the next tile, zero test
-#pragma unroll
-                    for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-                        for (int m = 0; m < KT; ++m)
-                            acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][pp][m]),
-                                                                                         __builtin_bit_cast(bf16x8, b0), acc[m][4 * hf + t], 0, 0, 0);
-                    float hs[8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { hs[2 * q] = __uint_as_float(b0[q] << 16); hs[2 * q + 1] = __uint_as_float(b0[q] & 0xffff0000u); }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = v[e] - hs[e];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b1[q] = x3_cvt2(r[2 * q], r[2 * q + 1]);
-                    if (t + 1 < 4) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) hi_next[q] = x3_cvt2(x[p][hf][2 * q][t + 1], x[p][hf][2 * q + 1][t + 1]);
-                    }
-                    const unsigned rest5 = (b1[0] | b1[1] | b1[2] | b1[3]) & 0x7fff7fffu;
-#pragma unroll
-                    for (int i = 0; i < 3 * KT - 1; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    if (__builtin_amdgcn_ballot_w64(rest5 != 0u) != 0ull) {
-                        // ---- block 2: 2 KT mid products, KT lo products || unpack(mid), s = r - mid, lo = cvt(s)
-#pragma unroll
-                        for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                            for (int m = 0; m < KT; ++m)
-                                acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][pp][m]),
-                                                                                             __builtin_bit_cast(bf16x8, b1), acc[m][4 * hf + t], 0, 0, 0);
-                        float ms[8], sres[8];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { ms[2 * q] = __uint_as_float(b1[q] << 16); ms[2 * q + 1] = __uint_as_float(b1[q] & 0xffff0000u); }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) sres[e] = r[e] - ms[e];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) b2[q] = x3_cvt2(sres[2 * q], sres[2 * q + 1]);
-#pragma unroll
-                        for (int m = 0; m < KT; ++m)
-                            acc[m][4 * hf + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][0][m]),
-                                                                                         __builtin_bit_cast(bf16x8, b2), acc[m][4 * hf + t], 0, 0, 0);
-#pragma unroll
-                        for (int i = 0; i < 2 * KT; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
-                        }
-#pragma unroll
-                        for (int i = 0; i < KT; ++i) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    }
-                }
-            } else
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v[8];
@@ -329,11 +260,11 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            x3_stage<KT, NH, false, (ABL == 5 ? 5 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
+            x3_stage<KT, NH, false>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
             __syncthreads();
             ++t;
         }
-        x3_stage<KT, NH, true, (ABL == 5 ? 5 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
+        x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
         float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;
@@ -396,9 +327,7 @@ __device__ __forceinline__ void sg_flush_tile16(float* __restrict__ tr, const f3
 // pieces keep their [.][KP] layout and every consumer is unchanged.  12.5 % fewer MFMAs at K = 105.
 // (A variant WITHOUT the zero-plane test -- on full significands it always fails, and without the branch a 64-column group
 // is one basic block for the scheduler -- was 3 % slower in A/B, cfg3 and K = 105: the test stays.)
-// PIN: the split written stage-wise and the issue order pinned with sched_group_barrier -- one 16-cycle MFMA, then 2-3 of the
-// split's VALU ops -- instead of the compiler's own interleave.
-template <int KT, int NH, int M16A = 2 * KT, bool PIN = false>
+template <int KT, int NH, int M16A = 2 * KT>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
                             int64_t ldS, SweepGeom g)
@@ -523,62 +452,6 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = x[cg][e][t];
-                    if constexpr (PIN) {
-                        u32x4 b0, b1, b2;
-                        float r[8];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) b0[q] = x3_cvt2(v[2 * q], v[2 * q + 1]);
-                        // ---- block 1: 3 M16A hi products || unpack(hi), r = x - hi, mid = cvt(r), zero test
-#pragma unroll
-                        for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-                            for (int m = 0; m < M16A; ++m)
-                                acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
-                                                                                             __builtin_bit_cast(bf16x8, b0), acc[m][4 * cg + t], 0, 0, 0);
-                        float hs[8];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { hs[2 * q] = __uint_as_float(b0[q] << 16); hs[2 * q + 1] = __uint_as_float(b0[q] & 0xffff0000u); }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) r[e] = v[e] - hs[e];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) b1[q] = x3_cvt2(r[2 * q], r[2 * q + 1]);
-                        const unsigned restp = (b1[0] | b1[1] | b1[2] | b1[3]) & 0x7fff7fffu;
-                        __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
-#pragma unroll
-                        for (int i = 0; i < 3 * M16A - 1; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, (23 + 3 * M16A - 2) / (3 * M16A - 1), 0);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        if (__builtin_amdgcn_ballot_w64(restp != 0u) != 0ull) {
-                            // ---- block 2: 2 M16A mid products, M16A lo products || unpack(mid), s = r - mid, lo = cvt(s)
-#pragma unroll
-                            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                                for (int m = 0; m < M16A; ++m)
-                                    acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pp][m]),
-                                                                                                 __builtin_bit_cast(bf16x8, b1), acc[m][4 * cg + t], 0, 0, 0);
-                            float ms[8], sres[8];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { ms[2 * q] = __uint_as_float(b1[q] << 16); ms[2 * q + 1] = __uint_as_float(b1[q] & 0xffff0000u); }
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) sres[e] = r[e] - ms[e];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) b2[q] = x3_cvt2(sres[2 * q], sres[2 * q + 1]);
-#pragma unroll
-                            for (int m = 0; m < M16A; ++m)
-                                acc[m][4 * cg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0][m]),
-                                                                                             __builtin_bit_cast(bf16x8, b2), acc[m][4 * cg + t], 0, 0, 0);
-#pragma unroll
-                            for (int i = 0; i < 2 * M16A; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x2, (20 + 2 * M16A - 1) / (2 * M16A), 0);
-                            }
-#pragma unroll
-                            for (int i = 0; i < M16A; ++i) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        }
-                        continue;
-                    }
                     u32x4 b[3];
                     x3_split8_scalar(v, b);
 #pragma unroll

@@ -229,6 +229,8 @@ int alpine_eval_recon_direct(alpine_ctx* ctx, double* out);
 /* Measurement: when enabled, hipEvents bracket every launch of the two streaming sweeps and every all-reduce the
  * library enqueues (the latter: transfer + waiting for the slowest rank). */
 enum { ALPINE_KERNEL_SWEEP_XHT = 0, ALPINE_KERNEL_SWEEP_WTX = 1, ALPINE_KERNEL_ALLREDUCE = 2, ALPINE_KERNEL_COUNT = 3 };
+/* enabled: 0 = off, 1 = every launch, n > 1 = the launches of every n-th iteration only (an event record between two kernels
+ * costs the stream about 2 us, which matters for sub-millisecond iterations). */
 int alpine_set_profiling(alpine_ctx* ctx, int enabled);
 int alpine_get_kernel_time(alpine_ctx* ctx, int which, double* total_ms, int64_t* launches);
 
