@@ -478,7 +478,7 @@ def main():
             "avg_ms_xht": m["ms_a"] / max(1, m["n_a"]), "avg_ms_wtx": m["ms_b"] / max(1, m["n_b"]),
             "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
             "tflops": ach_tf, "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS,
-            "sweeps_share_of_step": (m["ms_a"] + m["ms_b"]) / (1e3 * m["dt"]) if m["dt"] > 0 else 0.0,
+            "sweeps_share_of_step": ((m["ms_a"] / max(1, m["n_a"]) + m["ms_b"] / max(1, m["n_b"])) / (1e3 * m["dt"] / args.steps)) if m["dt"] > 0 else 0.0,
         }
 
     main_m = measure(args.dtype)
