@@ -958,8 +958,13 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
             tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
             h_bytes_mfma += tail.ybuf_rows ? hstats_tail_bytes(max_k, max_ct) : 2 * hstats_group_bytes(max_k, max_ct);
         }
-        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_mfma_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
-                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov, tail));
+        if (c->loss_type == ALPINE_LOSS_KL) {
+            DISPATCH_KT(c->KT, hipLaunchKernelGGL((h_update_mfma_kernel<KT_, 0>), dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
+                                                   c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov, tail));
+        } else {
+            DISPATCH_KT(c->KT, hipLaunchKernelGGL((h_update_mfma_kernel<KT_, 1>), dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
+                                                   c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov, tail));
+        }
     }
     HIPCHK(c, hipGetLastError());
     c->tail_valid = with_tail && !c->h_update_valu;

@@ -444,6 +444,51 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Wave-wide sums on the DPP path (no LDS crossbar: __shfl_xor is a ds_bpermute with ~100 cycles of latency per step, six
+// dependent steps per sum): quad_perm, row_shr:4, row_shr:8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31
+// across rows; the total lands in lane 63 and is broadcast with v_readlane.  Fixed order -> reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_f32_dpp(float v)
+{
+    v += dpp_mov_f32<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov_f32<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov_f32<0x114, 0xf>(v);     // row_shr:4
+    v += dpp_mov_f32<0x118, 0xf>(v);     // row_shr:8
+    v += dpp_mov_f32<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_mov_f32<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v)
+{
+    v += dpp_mov_f64<0xb1, 0xf>(v);
+    v += dpp_mov_f64<0x4e, 0xf>(v);
+    v += dpp_mov_f64<0x114, 0xf>(v);
+    v += dpp_mov_f64<0x118, 0xf>(v);
+    v += dpp_mov_f64<0x142, 0xa>(v);
+    v += dpp_mov_f64<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// num / den as num * v_rcp_f32(den) (<= 1 ulp reciprocal, so <= 2 ulp quotient) instead of the 11-instruction IEEE division
+// sequence: the multiplicative updates divide every element of W and H once per iteration, and in the latency-bound update
+// kernels (one wave per SIMD at shard sizes) the 32 divisions of a lane were 2.4 us of a 37 us block (in-kernel stamps).
+// den is clamped from below by eps in every caller, so the reciprocal's range is harmless.
+__device__ __forceinline__ float fast_div(float num, float den) { return num * __builtin_amdgcn_rcpf(den); }
+
 __device__ __forceinline__ float lane_bcast(float v, int src)   // src must be a compile-time constant
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -987,21 +1032,21 @@ __device__ __forceinline__ void sg_sum_pieces_rows(const float* __restrict__ pie
                                                    float* __restrict__ tr, int lane, f32x4 (&out)[KT][4])
 {
     constexpr int KP = 32 * KT, LD = KP + 4, Q4 = KP / 4, NI = (32 * Q4) / 64;
-    f32x4 acc[NI];
-    {
-        const float* base = pieces + sg_piece_offset(g, w_lo, ft, KP) + (int64_t)fl0 * KP;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] = *reinterpret_cast<const f32x4*>(base + 4 * (64 * i + lane));
-    }
     // UNR pieces (UNR * NI 1-KiB loads per wave) in flight per trip: on the fixed stream-K grid a tile has ~10 pieces at
-    // every shard size and a trip per piece costs one full memory latency; the adds stay in ascending workgroup order
-    constexpr int UNR = KT <= 2 ? 4 : 2;
-    int w = w_lo + 1;
+    // every shard size and a trip per piece costs one full memory latency (measured with in-kernel stamps: 10.7 us of a
+    // 40 us block at 25 000 cells with 1 + 4 + 4 + 1 + 1 trips); the adds stay in ascending workgroup order.
+    constexpr int UNR = KT <= 2 ? 5 : 2;
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t off_lo = sg_piece_offset(g, w_lo, ft, KP);          // the first workgroup's piece index needs the division
+    auto piece = [&](int w) { return pieces + (w == w_lo ? off_lo : sg_piece_offset_inner(g, w, KP)) + (int64_t)fl0 * KP; };
+    int w = w_lo;
     for (; w + UNR - 1 <= w_hi; w += UNR) {
         f32x4 v[UNR][NI];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const float* bu = pieces + sg_piece_offset_inner(g, w + u, KP) + (int64_t)fl0 * KP;
+            const float* bu = piece(w + u);
 #pragma unroll
             for (int i = 0; i < NI; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(bu + 4 * (64 * i + lane));
         }
@@ -1010,8 +1055,23 @@ __device__ __forceinline__ void sg_sum_pieces_rows(const float* __restrict__ pie
 #pragma unroll
             for (int i = 0; i < NI; ++i) acc[i] += v[u][i];
     }
-    for (; w <= w_hi; ++w) {
-        const float* base = pieces + sg_piece_offset_inner(g, w, KP) + (int64_t)fl0 * KP;
+    if (w + 1 <= w_hi) {                                              // 2 .. UNR-1 pieces left: pairs
+        for (; w + 1 <= w_hi; w += 2) {
+            const float* b0 = piece(w);
+            const float* b1 = piece(w + 1);
+            f32x4 v0[NI], v1[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v0[i] = *reinterpret_cast<const f32x4*>(b0 + 4 * (64 * i + lane));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v1[i] = *reinterpret_cast<const f32x4*>(b1 + 4 * (64 * i + lane));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] += v0[i];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] += v1[i];
+        }
+    }
+    if (w <= w_hi) {
+        const float* base = piece(w);
         f32x4 v[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const f32x4*>(base + 4 * (64 * i + lane));
@@ -1133,16 +1193,16 @@ __device__ __forceinline__ void hstats_tail(const float* __restrict__ trall, int
                 const int c = p / ki, k = p % ki;
                 float v = zbuf[c][lane] * hbuf[k][lane];
                 v = fmaf(zbuf[c][lane + 64], hbuf[k][lane + 64], v);
-                v = wave_sum_f32(v);
+                v = wave_sum_f32_dpp(v);
                 if (lane == 0) so[(c0 + c) * ki + k] = v;
             }
         }
         for (int k = wave; k < ki; k += 4) {
             float v = lam * hbuf[k][lane] + lam * hbuf[k][lane + 64];
-            v = wave_sum_f32(v);
+            v = wave_sum_f32_dpp(v);
             if (lane == 0) so[Ci * ki + k] = v;
         }
-        const double ws = wave_sum_f64(lacc);                  // waves 2, 3 hold zeros
+        const double ws = wave_sum_f64_dpp(lacc);                  // waves 2, 3 hold zeros
         if (lane == 0) lred[wave] = ws;
         __syncthreads();
         if (tid == 0) {
@@ -1161,7 +1221,9 @@ struct HTail {
     int ybuf_rows;          // rows of Y the block copies into LDS (all of them when they fit HT_YROWS_MAX, else 0 = read Y from global)
 };
 
-template <int KT>
+// LOSS: 0 = KL, 1 = Frobenius guided terms (a template parameter: as a run-time select every element of the guided loops
+// computed both forms and picked one).
+template <int KT, int LOSS>
 __global__ __launch_bounds__(256, (KT <= 2 ? 2 : 1))
 void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
                           const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
@@ -1239,38 +1301,46 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
             for (int m = 0; m < KT; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xreg[m][q] = 2.f * xreg[m][q];
+            // A covariate's k_i components live in [off, off + k_i): of the 8 groups of 8 components that a lane pair (h = 0, 1)
+            // holds in a k tile only those that overlap the range are touched (wave-uniform branches on scalars) -- with
+            // k_i = 5 that is one group of 8 instead of all 64 components, per covariate and class (in-kernel stamps: the
+            // guided terms were 10.6 us of a 40 us block when every group ran through selects).
             for (int i = 0; i < meta.n_cov; ++i) {
                 if (only_cov >= 0 && i != only_cov) continue;
-                const int off = meta.off[i], ki = meta.k[i], Ci = meta.lev[i], bo = meta.boff[i];
-                const float lam = (meta.loss_type == 0) ? meta.lam[i] : meta.lam2[i];
+                const int off = meta.off[i], ki = meta.k[i], Ci = meta.lev[i], bo = meta.boff[i], yo = meta.yoff[i];
+                const float lam = (LOSS == 0) ? meta.lam[i] : meta.lam2[i];
                 for (int cl = 0; cl < Ci; ++cl) {
                     const float* brow = Bl + bo + cl * ki - off;            // brow[k] = B_i[cl][k - off]
                     float part = 0.f;
 #pragma unroll
                     for (int m = 0; m < GT; ++m)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 4; ++q) {
+                            if (32 * m + 8 * q + 8 <= off || 32 * m + 8 * q >= off + ki) continue;      // wave-uniform
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int k = 32 * m + 8 * q + 4 * h + e;
                                 const float coef = (k >= off && k < off + ki) ? brow[k] : 0.f;
                                 part = fmaf(coef, hreg[m][q][e], part);
                             }
+                        }
                     const float bh = part + __shfl_xor(part, 32, 64);
-                    const float y = y_lds ? ybuf[(meta.yoff[i] + cl) * HS_CELLS + wave * 32 + c]
-                                          : (valid ? Y[(int64_t)(meta.yoff[i] + cl) * Np + n] : 0.f);
-                    const float z = (meta.loss_type == 0) ? y / fmaxf(bh, eps) : y;
+                    const float y = y_lds ? ybuf[(yo + cl) * HS_CELLS + wave * 32 + c]
+                                          : (valid ? Y[(int64_t)(yo + cl) * Np + n] : 0.f);
+                    const float z = (LOSS == 0) ? y / fmaxf(bh, eps) : y;
 #pragma unroll
                     for (int m = 0; m < GT; ++m)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 4; ++q) {
+                            if (32 * m + 8 * q + 8 <= off || 32 * m + 8 * q >= off + ki) continue;      // wave-uniform
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int k = 32 * m + 8 * q + 4 * h + e;
                                 const float lb = (k >= off && k < off + ki) ? lam * brow[k] : 0.f;
                                 xreg[m][q][e] = fmaf(lb, z, xreg[m][q][e]);
-                                acc[m][4 * q + e] = (meta.loss_type == 0) ? acc[m][4 * q + e] + lb : fmaf(lb, bh, acc[m][4 * q + e]);
+                                acc[m][4 * q + e] = (LOSS == 0) ? acc[m][4 * q + e] + lb : fmaf(lb, bh, acc[m][4 * q + e]);
                             }
+                        }
                 }
             }
 
@@ -1281,7 +1351,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                     const int k4 = 32 * m + 8 * q + 4 * h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = hreg[m][q][e] * (xreg[m][q][e] / fmaxf(acc[m][4 * q + e], eps));
+                        const float v = hreg[m][q][e] * fast_div(xreg[m][q][e], fmaxf(acc[m][4 * q + e], eps));
                         const int k = k4 + e;
                         if (k >= k_lo && k < k_hi) hreg[m][q][e] = v;           // outside the range (and pads, which are 0): unchanged
                         if (with_tail && !valid) hreg[m][q][e] = 0.f;           // rows past the last cell must not enter the sums of the tail
@@ -1394,7 +1464,7 @@ void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, 
             for (int e = 0; e < 4; ++e) {
                 const int k = k4 + e;
                 const float d = fmaxf(acc[m][4 * q + e] + l1, eps);
-                const float v = wreg[m][q][e] * ((2.f * xreg[m][q][e]) / d);
+                const float v = wreg[m][q][e] * fast_div(2.f * xreg[m][q][e], d);
                 if (k >= k_lo && k < k_hi) wreg[m][q][e] = v;
                 if (!valid) wreg[m][q][e] = 0.f;                                      // pad rows stay exactly zero
             }
