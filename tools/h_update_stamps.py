@@ -1,0 +1,110 @@
+"""Where does a block of h_update_mfma_kernel spend its time?  In-kernel stamps (s_memrealtime, 10 ns ticks) in a THROWAWAY
+build of the library: `build` patches a copy of alpine_amd/csrc under /tmp with a `g_stamps` device array and STAMP(i) marks
+at the phase boundaries of the H update and compiles tools/libalpine_stamp.so (needs hipcc, no GPU); `run` (on the GPU box)
+loads that library through ALPINE_HIP_LIBRARY, runs a few iterations of the cfg3 workload at --cells and prints the median
+duration of every phase over the blocks of the last H update.  The product library carries no stamps.
+
+    python tools/h_update_stamps.py build            # build container
+    gpurun -- python tools/h_update_stamps.py run 25000
+
+Round 2, 25 000 cells (one of 8 shards of cfg3), per block of 128 cells: fills + barrier 2.8 us | pieces (11 per tile) + H tile
+10.9 | 2W^TW.H on the MFMA 2.8 | guided terms + update 9.3 -> 8.1 (group-uniform loops) | store 1.0 | barrier + H H^T partial 3.6 |
+statistics 8.2 -> 6.6 (DPP sums) | total 40 -> 36 us; the MFMA phase shows the clock: 64 MFMAs x 64 cycles in 2.7 us = 1.5 GHz."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(REPO, "tools", "libalpine_stamp.so")
+MARKS = [   # (text to find inside h_update_mfma_kernel, replacement)
+    ("    const bool y_lds = tail.ybuf_rows > 0;", "    const bool y_lds = tail.ybuf_rows > 0;\n    STAMP(0);"),
+    ("    for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];\n    __syncthreads();\n",
+     "    for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];\n    __syncthreads();\n    STAMP(1);\n"),
+    ("                tile_raw_to_cd<KT>(hraw, tr, lane, hreg);\n            }\n",
+     "                tile_raw_to_cd<KT>(hraw, tr, lane, hreg);\n            }\n            STAMP(2);\n"),
+    ("            // numerator = 2 W^TX (+ guided)", "            asm volatile(\"s_nop 0\" :: \"v\"(acc[0][0]));\n            STAMP(3);\n            // numerator = 2 W^TX (+ guided)"),
+    ("            (void)K;", "            (void)K;\n            STAMP(4);"),
+    ("        __syncthreads();                                                       // the four tiles of this group are in LDS\n",
+     "        STAMP(5);\n        __syncthreads();                                                       // the four tiles of this group are in LDS\n"),
+    ("        if (meta.n_cov > 0) {\n            if (y_lds) {", "        STAMP(6);\n        if (meta.n_cov > 0) {\n            if (y_lds) {"),
+    ("                             hs_smem, tid >> 7, grp);\n            }\n        }\n    }\n}",
+     "                             hs_smem, tid >> 7, grp);\n            }\n        }\n        STAMP(7);\n    }\n}"),
+]
+PHASES = ["Y / 2W^TW / B fills + barrier", "H issue + pieces + H to C/D", "2W^TW.H on the MFMA", "guided terms + update", "tile store",
+          "barrier + H H^T partial", "covariate statistics"]
+
+
+def build():
+    work = "/tmp/alpine_stamp_build"
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(os.path.join(work, "alpine_amd"))
+    shutil.copytree(os.path.join(REPO, "alpine_amd", "csrc"), os.path.join(work, "alpine_amd", "csrc"))
+    shutil.copytree(os.path.join(REPO, "include"), os.path.join(work, "include"))
+    kp = os.path.join(work, "alpine_amd", "csrc", "kernels.hpp")
+    s = open(kp).read()
+    s = s.replace("namespace alpine {\n\ntypedef float f32x4",
+                  "namespace alpine {\n__device__ unsigned long long g_stamps[16 * 8192];\n#define STAMP(i) do { if (threadIdx.x == 0) "
+                  "g_stamps[16 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)\n\ntypedef float f32x4", 1)
+    k = s.index("void h_update_mfma_kernel(")
+    body = s[k:]
+    for a, b in MARKS:
+        assert a in body, f"source changed, mark not found: {a[:50]!r}"
+        body = body.replace(a, b, 1)
+    open(kp, "w").write(s[:k] + body)
+    hp = os.path.join(work, "alpine_amd", "csrc", "alpine_hip.hip")
+    open(hp, "a").write('\nextern "C" int alpine_debug_read_stamps(unsigned long long* host, int n)\n{\n    return (int)hipMemcpyFromSymbol('
+                        'host, HIP_SYMBOL(alpine::g_stamps), sizeof(unsigned long long) * n);\n}\n')
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
+                    "-fno-slp-vectorize", "-o", LIB, hp, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    print(LIB)
+
+
+def run(cells):
+    os.environ["ALPINE_HIP_LIBRARY"] = LIB
+    sys.path.insert(0, REPO)
+    import torch
+    import bench
+    from alpine_amd import _native
+    from alpine_amd.datasets import synth_counts_device_chunks
+    from alpine_amd.model import draw_initial_factors
+    wl = dict(bench.WORKLOADS["cfg3"])
+    G, N, ku, kcov = wl["genes"], cells, wl["ku"], wl["kcov"]
+    dev = torch.device("cuda", 0)
+    W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], [2, 2])
+    eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=[2, 2], lam=[1e3, 1e3],
+                              orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype="x3")
+    for off, chunk in synth_counts_device_chunks(N, G, rank=ku, seed=0, device=dev, chunk_cells=8192):
+        torch.cuda.synchronize()
+        eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
+        eng.synchronize()
+    eng.finalize_X()
+    for i in range(2):
+        eng.upload_Y(i, bench.labels_onehot(N, seed=1 + i))
+    eng.set_factors(W0, H0, B0)
+    eng.run(10, with_loss=True)
+    eng.synchronize()
+    lib = _native.load()
+    nb = (N + 127) // 128
+    buf = (C.c_ulonglong * (16 * nb))()
+    lib.alpine_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+    assert lib.alpine_debug_read_stamps(buf, 16 * nb) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 16)[:, :8].astype(np.int64)
+    d = np.diff(a, axis=1) / 100.0
+    print(f"cells {N}: {nb} blocks, kernel span (first block start -> last block end) {(a[:, 7].max() - a[:, 0].min()) / 100.0:.1f} us")
+    for i, n in enumerate(PHASES):
+        print(f"  {n:32s} median {np.median(d[:, i]):6.2f} us   p90 {np.percentile(d[:, i], 90):6.2f}")
+    print(f"  block total: median {np.median((a[:, 7] - a[:, 0]) / 100.0):.2f} us; start skew p90 - p10 {(np.percentile(a[:, 0], 90) - np.percentile(a[:, 0], 10)) / 100.0:.2f} us")
+    eng.close()
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+    elif len(sys.argv) > 1 and sys.argv[1] == "run":
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 25000)
+    else:
+        sys.exit(__doc__)
