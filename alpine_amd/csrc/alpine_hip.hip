@@ -116,6 +116,7 @@ struct alpine_ctx {
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     int x3_variant = -1;              // env ALPINE_HIP_X3_VARIANT: 0 = 32x32x16 MFMA, 2 = 16x16x32 (x3w), unset = chosen from the data
     bool x3_wide = false;             // the sweeps use stream_gemm_x3w_kernel (decided in alpine_finalize_X)
+    bool x3_narrow = false;
     double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
     // profiling
     bool prof = false;
@@ -305,7 +306,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;   // A/B of the workgroup shape, same results
     const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
     c->slots = slots;
-    const int sweep_bf = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
+    c->x3_narrow = getenv_is("ALPINE_HIP_X3_NARROW", '1');          // A/B: 512-column workgroup tiles at K <= 64 (half the piece bytes, twice the panel re-reads)
+    const int sweep_bf = c->x3 ? ((c->KT <= 2 && !c->x3_narrow) ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
     c->sweep_bf = sweep_bf;
     c->batch_cap = cfg->batch_capacity;
     c->geomA = make_geom(Gp, Np, slots, cfg->split_a, sweep_bf);       // XH^T: f = genes, r = cells
@@ -784,7 +786,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
             switch (c->KT) {
                 case 1: X3W_LAUNCH(1, 2); break;
-                case 2: X3W_LAUNCH(2, 2); break;
+                case 2: if (c->x3_narrow) X3W_LAUNCH(2, 1); else X3W_LAUNCH(2, 2); break;
                 case 3: X3W_LAUNCH(3, 1); break;
                 default: X3W_LAUNCH(4, 1); break;
             }
@@ -800,7 +802,8 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
                 if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
 #endif
-                hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
             default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
