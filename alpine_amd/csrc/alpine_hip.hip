@@ -306,7 +306,12 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;   // A/B of the workgroup shape, same results
     const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
     c->slots = slots;
-    c->x3_narrow = getenv_is("ALPINE_HIP_X3_NARROW", '1');          // A/B: 512-column workgroup tiles at K <= 64 (half the piece bytes, twice the panel re-reads)
+    // K <= 64: 1024-column workgroup tiles (a wave owns 256 columns) -- except for small shards, where the piece traffic (every
+    // workgroup flushes bf x KP accumulators whatever the shard size: 67 MB per sweep at 1024 columns) outweighs the doubled panel
+    // re-reads of 512-column tiles: interleaved A/B at 25 000 cells 0.7436 vs 0.7510 ms per iteration (-1 %; the sweep itself is
+    // 1.2 % slower), at 200 000 cells +0.8 %.  ALPINE_HIP_X3_NARROW=0|1 forces one form.
+    if (const char* e = std::getenv("ALPINE_HIP_X3_NARROW")) c->x3_narrow = (e[0] == '1');
+    else c->x3_narrow = cfg->n_cells <= 32768;
     const int sweep_bf = c->x3 ? ((c->KT <= 2 && !c->x3_narrow) ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
     c->sweep_bf = sweep_bf;
     c->batch_cap = cfg->batch_capacity;
