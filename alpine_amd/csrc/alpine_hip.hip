@@ -312,6 +312,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     // 1.2 % slower), at 200 000 cells +0.8 %.  ALPINE_HIP_X3_NARROW=0|1 forces one form.
     if (const char* e = std::getenv("ALPINE_HIP_X3_NARROW")) c->x3_narrow = (e[0] == '1');
     else c->x3_narrow = cfg->n_cells <= 32768;
+    if (c->x3_ablate) c->x3_narrow = false;          // the diagnostics build's ablated kernels exist for the 1024-column form only
     const int sweep_bf = c->x3 ? ((c->KT <= 2 && !c->x3_narrow) ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
     c->sweep_bf = sweep_bf;
     c->batch_cap = cfg->batch_capacity;
@@ -790,7 +791,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
             switch (c->KT) {
-                case 1: X3W_LAUNCH(1, 2); break;
+                case 1: if (c->x3_narrow) X3W_LAUNCH(1, 1); else X3W_LAUNCH(1, 2); break;
                 case 2: if (c->x3_narrow) X3W_LAUNCH(2, 1); else X3W_LAUNCH(2, 2); break;
                 case 3: X3W_LAUNCH(3, 1); break;
                 default: X3W_LAUNCH(4, 1); break;
@@ -800,7 +801,10 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
             return 0;
         }
         switch (c->KT) {
-            case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            case 1:
+                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                break;
             case 2:
 #ifdef ALPINE_DIAGNOSTICS
                 if (c->x3_ablate == 1) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }

@@ -839,3 +839,23 @@ def test_trace_form_loss_cancellation_bound_on_a_near_exact_fit():
         eng.close()
         assert direct < 5e-6 * xn                  # the fit really is near exact: recon / ||X||^2 ~ 1e-6
         assert abs(trace - direct) <= 1e-6 * xn, (x_dtype, trace, direct, xn)
+
+
+@pytest.mark.parametrize("name", ["kl_2cov_nan", "counts_2cov", "k74", "kl_1cov"])
+def test_x3_tile_width_forms_agree_with_the_reference(name, monkeypatch):
+    """The x3 sweeps pick 512-column workgroup tiles for shards of <= 32 768 cells (less piece traffic) and 1024-column tiles
+    above; every golden case is small, so the 1024-column kernels are forced here as well.  Both forms, both matrix
+    instructions (the gamma cases take x3w, counts_2cov the 32x32x16 form): reference tolerances."""
+    c = load_case(name)
+    res = {}
+    for narrow in ("1", "0"):
+        monkeypatch.setenv("ALPINE_HIP_X3_NARROW", narrow)
+        eng = make_engine(c, x_dtype="x3")
+        monkeypatch.delenv("ALPINE_HIP_X3_NARROW")
+        eng.run(c.T, with_loss=True)
+        res[narrow] = (eng.get_factors(), eng.losses())
+        eng.close()
+        W, H, Bs = res[narrow][0]
+        assert rel_fro(W, c.WT_unscaled) < 1e-4 and rel_fro(H, c.HT_unscaled) < 1e-4, (name, narrow)
+        assert_loss_rows_close(res[narrow][1], c.loss_history, n_cells=c.X.shape[0])
+    assert rel_fro(res["1"][0][0], res["0"][0][0]) < 2e-5 and rel_fro(res["1"][0][1], res["0"][0][1]) < 2e-5
