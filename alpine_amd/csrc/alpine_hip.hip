@@ -65,7 +65,8 @@ struct alpine_ctx {
     int* idx_dev = nullptr;
     int slots = 512;
     bool x3 = false;                  // ALPINE_FLAG_X3_PRODUCTS in effect (float32 X, exact bf16 plane products)
-    int64_t piecesA_cap = 0, piecesB_cap = 0;   // capacity of the pieces buffers, in (bf x KP) tiles
+    int64_t piecesA_cap = 0, piecesB_cap = 0;   // capacity of the pieces buffers, in floats (covers both tile widths of the x3 sweeps)
+    int split_a_hint = 0, split_b_hint = 0;     // alpine_config.split_a / split_b
     int sweep_bf = SG_BLOCK_F;        // f columns per sweep workgroup tile (SweepGeom::bf of every geometry of this ctx)
     int sweep_waves = 4;              // waves per sweep workgroup (8 for the bf16 sweeps with K <= 64)
     float* red = nullptr;
@@ -116,7 +117,8 @@ struct alpine_ctx {
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     int x3_variant = -1;              // env ALPINE_HIP_X3_VARIANT: 0 = 32x32x16 MFMA, 2 = 16x16x32 (x3w), unset = chosen from the data
     bool x3_wide = false;             // the sweeps use stream_gemm_x3w_kernel (decided in alpine_finalize_X)
-    bool x3_narrow = false;
+    bool x3_narrow = false;           // 512-column workgroup tiles at K <= 64 (in effect)
+    bool x3_narrow_pref = false;      // ... wanted for this shard size; alpine_finalize_X confirms it once the matrix instruction is known
     double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
     // profiling
     bool prof = false;
@@ -248,6 +250,15 @@ static int gram_rows_per_wave(int64_t R, int n_cu)
     return (int)std::min<int64_t>(GR_ROWS_PER_WAVE, rpw);
 }
 
+// (re)computes the stream-K geometry of the two sweeps over the whole shard for workgroup tiles of bf columns
+static void apply_sweep_geometry(alpine_ctx* c, int bf)
+{
+    c->sweep_bf = bf;
+    c->geomA = make_geom(c->Gp, c->Np, c->slots, c->split_a_hint, bf);       // XH^T: f = genes, r = cells
+    c->geomB = make_geom(c->Np, c->Gp, c->slots, c->split_b_hint, bf);       // W^TX: f = cells, r = genes
+    c->full.gA = c->geomA; c->full.gB = c->geomB;
+}
+
 // ---------------------------------------------------------------------------------- create
 static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& g)
 {
@@ -306,18 +317,30 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;   // A/B of the workgroup shape, same results
     const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
     c->slots = slots;
-    // K <= 64: 1024-column workgroup tiles (a wave owns 256 columns) -- except for small shards, where the piece traffic (every
-    // workgroup flushes bf x KP accumulators whatever the shard size: 67 MB per sweep at 1024 columns) outweighs the doubled panel
-    // re-reads of 512-column tiles: interleaved A/B at 25 000 cells 0.7436 vs 0.7510 ms per iteration (-1 %; the sweep itself is
-    // 1.2 % slower), at 200 000 cells +0.8 %.  ALPINE_HIP_X3_NARROW=0|1 forces one form.
-    if (const char* e = std::getenv("ALPINE_HIP_X3_NARROW")) c->x3_narrow = (e[0] == '1');
-    else c->x3_narrow = cfg->n_cells <= 32768;
-    if (c->x3_ablate) c->x3_narrow = false;          // the diagnostics build's ablated kernels exist for the 1024-column form only
-    const int sweep_bf = c->x3 ? ((c->KT <= 2 && !c->x3_narrow) ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
-    c->sweep_bf = sweep_bf;
+    // K <= 64: 1024-column workgroup tiles (a wave owns 256 columns) -- except for small shards on the 32x32x16 form, where the
+    // piece traffic (every workgroup flushes bf x KP accumulators whatever the shard size: 67 MB per sweep at 1024 columns,
+    // written and read back) outweighs the doubled panel re-reads of 512-column tiles.  Interleaved A/B, ms per iteration, 512 vs
+    // 1024 columns: 25 000 cells 0.7436 vs 0.7510, 50 000 cells 1.360 vs 1.399, 100 000 cells 2.680 vs 2.640, 200 000 cells
+    // +0.8 %; on the 16x16x32 form (x3w) 512 columns LOSE at 25 000 cells (0.794 vs 0.779).  So: 512 columns for shards of
+    // <= 65 536 cells unless alpine_finalize_X selects x3w.  ALPINE_HIP_X3_NARROW=0|1 forces one form.
+    if (const char* e = std::getenv("ALPINE_HIP_X3_NARROW")) c->x3_narrow_pref = (e[0] == '1');
+    else c->x3_narrow_pref = cfg->n_cells <= 65536;
+    if (c->x3_ablate || !c->x3 || c->KT > 2) c->x3_narrow_pref = false;   // (the diagnostics build's ablated kernels are 1024-column only)
     c->batch_cap = cfg->batch_capacity;
-    c->geomA = make_geom(Gp, Np, slots, cfg->split_a, sweep_bf);       // XH^T: f = genes, r = cells
-    c->geomB = make_geom(Np, Gp, slots, cfg->split_b, sweep_bf);       // W^TX: f = cells, r = genes
+    c->split_a_hint = cfg->split_a; c->split_b_hint = cfg->split_b;
+    // pieces: nwg * maxp tiles of bf x KP floats; mini-batch views have their own geometry, bounded by nft + 2 * nwg + maxp
+    // pieces.  Sized for every tile width this ctx may use.
+    auto piece_floats = [&](int bf, int64_t* capA, int64_t* capB) {
+        const SweepGeom a = make_geom(Gp, Np, slots, cfg->split_a, bf), b = make_geom(Np, Gp, slots, cfg->split_b, bf);
+        int64_t ta = (int64_t)a.nwg * a.maxp, tb = (int64_t)b.nwg * b.maxp;
+        if (c->batch_cap > 0) { ta = std::max<int64_t>(ta, (int64_t)a.nft + 2 * slots + 8); tb = std::max<int64_t>(tb, (int64_t)b.nft + 2 * slots + 8); }
+        *capA = std::max(*capA, ta * bf * KP); *capB = std::max(*capB, tb * bf * KP);
+    };
+    const int bf_default = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
+    piece_floats(bf_default, &c->piecesA_cap, &c->piecesB_cap);
+    if (c->x3_narrow_pref) piece_floats(512, &c->piecesA_cap, &c->piecesB_cap);
+    c->x3_narrow = c->x3_narrow_pref;                 // until alpine_finalize_X knows the data
+    apply_sweep_geometry(c, c->x3_narrow ? 512 : bf_default);
 
     ALLOC(c, c->Xgn, float, c->bf16 ? 4 : Gp * Np);
     ALLOC(c, c->Xng, float, (c->transform_only || c->bf16) ? 4 : Np * Gp);
@@ -340,15 +363,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
     ALLOC(c, c->B[0], float, std::max(1, c->nB));
     ALLOC(c, c->B[1], float, std::max(1, c->nB));
-    // pieces: nwg * maxp tiles of bf x KP; mini-batch views have their own geometry, bounded by nft + 2 * nwg + maxp pieces
-    c->piecesA_cap = (int64_t)c->geomA.nwg * c->geomA.maxp;
-    c->piecesB_cap = (int64_t)c->geomB.nwg * c->geomB.maxp;
-    if (c->batch_cap > 0) {
-        c->piecesA_cap = std::max<int64_t>(c->piecesA_cap, (int64_t)c->geomA.nft + 2 * slots + 8);
-        c->piecesB_cap = std::max<int64_t>(c->piecesB_cap, (int64_t)c->geomB.nft + 2 * slots + 8);
-    }
-    ALLOC(c, c->piecesA, float, c->transform_only ? 4 : c->piecesA_cap * sweep_bf * KP);
-    ALLOC(c, c->piecesB, float, c->piecesB_cap * sweep_bf * KP);
+    ALLOC(c, c->piecesA, float, c->transform_only ? 4 : c->piecesA_cap);
+    ALLOC(c, c->piecesB, float, c->piecesB_cap);
     c->red_floats = g.red_floats; c->red_hht = g.red_hht; c->red_stats = g.red_stats;
     if (cfg->reduce_block) { c->red = (float*)cfg->reduce_block; c->own_red = false; HIPCHK(c, hipMemsetAsync(c->red, 0, sizeof(float) * c->red_floats, c->stream)); }
     else { ALLOC(c, c->red, float, c->red_floats); c->own_red = true; }
@@ -629,6 +645,11 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         // regimes and x3w never multiplies that tile: 11 % faster on full significands, 5 % on counts at K = 105)
         const bool pad_tile = c->K <= c->KP - 16;
         c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3)));
+        if (c->x3 && c->KT <= 2) {
+            // tile width (see alpine_create): 512 columns only for small shards on the 32x32x16 form
+            const bool narrow = c->x3_narrow_pref && (!c->x3_wide || std::getenv("ALPINE_HIP_X3_NARROW") != nullptr);
+            if (narrow != c->x3_narrow) { c->x3_narrow = narrow; apply_sweep_geometry(c, narrow ? 512 : 1024); c->tail_valid = false; }
+        }
     }
     c->x_final = true;
     return 0;
@@ -1289,7 +1310,7 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
     v.N = (int)n; v.Np = Bp;
     v.gA = make_geom(c->Gp, Bp, c->slots, 0, c->sweep_bf);
     v.gB = make_geom(Bp, c->Gp, c->slots, 0, c->sweep_bf);
-    if ((int64_t)v.gA.nwg * v.gA.maxp > c->piecesA_cap || (int64_t)v.gB.nwg * v.gB.maxp > c->piecesB_cap)
+    if ((int64_t)v.gA.nwg * v.gA.maxp * v.gA.bf * c->KP > c->piecesA_cap || (int64_t)v.gB.nwg * v.gB.maxp * v.gB.bf * c->KP > c->piecesB_cap)
         return fail(c, ALPINE_ERR_STATE, "internal: batch view needs more sweep pieces than were allocated");
     v.statBlocks = (int)((n + HS_CELLS - 1) / HS_CELLS);
     v.gramBlocksH = (int)((Bp + 4 * GR_ROWS_PER_WAVE - 1) / (4 * GR_ROWS_PER_WAVE));
