@@ -13,6 +13,8 @@ bash tools/profile_mode.sh split cfg3
 bash tools/profile_mode.sh bf16 cfg3
 export STATS_ONLY=1
 bash tools/profile_mode.sh x3 cfg3 shard8 --cells 25000
+bash tools/profile_mode.sh x3 cfg3 shard4 --cells 50000
+bash tools/profile_mode.sh x3 cfg3 shard2 --cells 100000
 bash tools/profile_mode.sh x3 cfg2
 bash tools/profile_mode.sh f32 cfg2
 bash tools/profile_mode.sh x3 cfg4 share8 --cells 125000
