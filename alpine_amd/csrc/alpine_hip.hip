@@ -833,7 +833,6 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
                 if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
 #endif
                 if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else if (c->x3_variant == 8) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 8>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
             case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;

@@ -94,81 +94,6 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
         }
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
-            if constexpr (ABL == 8) {
-                // GROUPED form: the split is cut into chunks of 4-5 mutually independent VALU ops (one stage of the chain
-                // cvt -> unpack -> subtract -> cvt ... for 2-4 pairs at a time) and every chunk is tied to one MFMA by
-                // sched_barrier(0) fences, so that each 32-cycle MFMA gap carries one chunk whose ops do not wait for each
-                // other, and a stage's results are at least one gap old when the next stage reads them.  The hi plane of
-                // tile t + 1 is converted inside tile t's block (software pipelining across tiles).
-                static_assert(ABL != 8 || KT == 2, "grouped form: K <= 64 instantiation only");
-                unsigned hi_next[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hi_next[q] = x3_cvt2(x[p][hf][2 * q][0], x[p][hf][2 * q + 1][0]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v[8], hs[8], r[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = x[p][hf][e][t];
-                    u32x4 b0, b1, b2;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b0[q] = hi_next[q];
-                    f32x16& A0 = acc[0][4 * hf + t];
-                    f32x16& A1 = acc[1][4 * hf + t];
-#define X3_MFMA(ACC, PP, M, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[cur][PP][M]), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
-#define X3_FENCE() __builtin_amdgcn_sched_barrier(0)
-                    X3_FENCE();
-                    X3_MFMA(A0, 0, 0, b0);                                                         // gap 1: unpack hi, pairs 0-1
-                    hs[0] = __uint_as_float(b0[0] << 16); hs[1] = __uint_as_float(b0[0] & 0xffff0000u);
-                    hs[2] = __uint_as_float(b0[1] << 16); hs[3] = __uint_as_float(b0[1] & 0xffff0000u);
-                    X3_FENCE();
-                    X3_MFMA(A1, 0, 1, b0);                                                         // gap 2: unpack hi, pairs 2-3
-                    hs[4] = __uint_as_float(b0[2] << 16); hs[5] = __uint_as_float(b0[2] & 0xffff0000u);
-                    hs[6] = __uint_as_float(b0[3] << 16); hs[7] = __uint_as_float(b0[3] & 0xffff0000u);
-                    X3_FENCE();
-                    X3_MFMA(A0, 1, 0, b0);                                                         // gap 3: r = x - hi, pairs 0-1 (+ next hi 0)
-                    r[0] = v[0] - hs[0]; r[1] = v[1] - hs[1]; r[2] = v[2] - hs[2]; r[3] = v[3] - hs[3];
-                    if (t + 1 < 4) hi_next[0] = x3_cvt2(x[p][hf][0][(t + 1) & 3], x[p][hf][1][(t + 1) & 3]);
-                    X3_FENCE();
-                    X3_MFMA(A1, 1, 1, b0);                                                         // gap 4: r, pairs 2-3 (+ next hi 1)
-                    r[4] = v[4] - hs[4]; r[5] = v[5] - hs[5]; r[6] = v[6] - hs[6]; r[7] = v[7] - hs[7];
-                    if (t + 1 < 4) hi_next[1] = x3_cvt2(x[p][hf][2][(t + 1) & 3], x[p][hf][3][(t + 1) & 3]);
-                    X3_FENCE();
-                    X3_MFMA(A0, 2, 0, b0);                                                         // gap 5: mid = cvt(r) (+ next hi 2)
-                    b1[0] = x3_cvt2(r[0], r[1]); b1[1] = x3_cvt2(r[2], r[3]); b1[2] = x3_cvt2(r[4], r[5]); b1[3] = x3_cvt2(r[6], r[7]);
-                    if (t + 1 < 4) hi_next[2] = x3_cvt2(x[p][hf][4][(t + 1) & 3], x[p][hf][5][(t + 1) & 3]);
-                    X3_FENCE();
-                    X3_MFMA(A1, 2, 1, b0);                                                         // gap 6: zero test (+ next hi 3)
-                    const unsigned rest8 = (b1[0] | b1[1] | b1[2] | b1[3]) & 0x7fff7fffu;
-                    if (t + 1 < 4) hi_next[3] = x3_cvt2(x[p][hf][6][(t + 1) & 3], x[p][hf][7][(t + 1) & 3]);
-                    X3_FENCE();
-                    if (__builtin_amdgcn_ballot_w64(rest8 != 0u) != 0ull) {
-                        float ms[8], sr[8];
-                        X3_FENCE();
-                        X3_MFMA(A0, 0, 0, b1);                                                     // gap 7: unpack mid, pairs 0-1
-                        ms[0] = __uint_as_float(b1[0] << 16); ms[1] = __uint_as_float(b1[0] & 0xffff0000u);
-                        ms[2] = __uint_as_float(b1[1] << 16); ms[3] = __uint_as_float(b1[1] & 0xffff0000u);
-                        X3_FENCE();
-                        X3_MFMA(A1, 0, 1, b1);                                                     // gap 8: unpack mid, pairs 2-3
-                        ms[4] = __uint_as_float(b1[2] << 16); ms[5] = __uint_as_float(b1[2] & 0xffff0000u);
-                        ms[6] = __uint_as_float(b1[3] << 16); ms[7] = __uint_as_float(b1[3] & 0xffff0000u);
-                        X3_FENCE();
-                        X3_MFMA(A0, 1, 0, b1);                                                     // gap 9: s = r - mid, pairs 0-1
-                        sr[0] = r[0] - ms[0]; sr[1] = r[1] - ms[1]; sr[2] = r[2] - ms[2]; sr[3] = r[3] - ms[3];
-                        X3_FENCE();
-                        X3_MFMA(A1, 1, 1, b1);                                                     // gap 10: s, pairs 2-3; lo pairs 0-1
-                        sr[4] = r[4] - ms[4]; sr[5] = r[5] - ms[5]; sr[6] = r[6] - ms[6]; sr[7] = r[7] - ms[7];
-                        b2[0] = x3_cvt2(sr[0], sr[1]); b2[1] = x3_cvt2(sr[2], sr[3]);
-                        X3_FENCE();
-                        b2[2] = x3_cvt2(sr[4], sr[5]); b2[3] = x3_cvt2(sr[6], sr[7]);                // lo pairs 2-3, then the lo products
-                        X3_FENCE();
-                        X3_MFMA(A0, 0, 0, b2);
-                        X3_MFMA(A1, 0, 1, b2);
-                        X3_FENCE();
-                    }
-#undef X3_MFMA
-#undef X3_FENCE
-                }
-            } else
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v[8];
@@ -335,11 +260,11 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            x3_stage<KT, NH, false, (ABL == 8 ? 8 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
+            x3_stage<KT, NH, false>(acc, x, &lds[t & 1][lds_lane], xrow0 + (t + 1) * x_stage, xrow1 + (t + 1) * x_stage, ldS, STAGE_BF16);
             __syncthreads();
             ++t;
         }
-        x3_stage<KT, NH, true, (ABL == 8 ? 8 : 0)>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
+        x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
         float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;
