@@ -6,6 +6,12 @@ duration of every phase over the blocks of the last H update.  The product libra
 
     python tools/h_update_stamps.py build            # build container
     gpurun -- python tools/h_update_stamps.py run 25000
+    gpurun -- python tools/h_update_stamps.py sweepclock [x_scale]      # in-kernel shader clock of the x3 / x3w sweeps
+
+`sweepclock`: the same throwaway build also stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) at the start of
+every sweep workgroup and after its last flush; after >= 2 s of back-to-back iterations the in-kernel clock is
+delta(s_memtime) / delta(s_memrealtime) x 100 MHz, median over the workgroups of the last launch (MI355X_MICROARCH.md, DVFS
+give-back item 6).  x_scale = 1 (counts, 32x32x16 form) or 0.3712345 (full significands, x3w).
 
 Round 2, 25 000 cells (one of 8 shards of cfg3), per block of 128 cells: fills + barrier 2.8 us | pieces (11 per tile) + H tile
 10.9 | 2W^TW.H on the MFMA 2.8 | guided terms + update 9.3 -> 8.1 (group-uniform loops) | store 1.0 | barrier + H H^T partial 3.6 |
@@ -34,6 +40,12 @@ MARKS = [   # (text to find inside h_update_mfma_kernel, replacement)
     ("                             hs_smem, tid >> 7, grp);\n            }\n        }\n    }\n}",
      "                             hs_smem, tid >> 7, grp);\n            }\n        }\n        STAMP(7);\n    }\n}"),
 ]
+SWEEP_MARKS = [   # (kernel name, start anchor, end anchor) in kernels_x3.hpp
+    ("void stream_gemm_x3_kernel(", "    const int first_tile = (int)(pos / g.R);\n",
+     "                sg_flush_tile<KT>(flush_tr[wave], d, out + (int64_t)(128 * hf + tt) * KP, 4 * KP, lane);\n            }\n        }\n"),
+    ("void stream_gemm_x3w_kernel(", "    const int first_tile = (int)(pos / g.R);\n",
+     "                sg_flush_tile16<KT>(flush_tr[wave], d, out + (int64_t)(64 * cg + tt) * KP, 4 * KP, lane);\n            }\n        }\n"),
+]
 PHASES = ["Y / 2W^TW / B fills + barrier", "H issue + pieces + H to C/D", "2W^TW.H on the MFMA", "guided terms + update", "tile store",
           "barrier + H H^T partial", "covariate statistics"]
 
@@ -55,9 +67,23 @@ def build():
         assert a in body, f"source changed, mark not found: {a[:50]!r}"
         body = body.replace(a, b, 1)
     open(kp, "w").write(s[:k] + body)
+    xp = os.path.join(work, "alpine_amd", "csrc", "kernels_x3.hpp")
+    x = open(xp).read()
+    x = x.replace("namespace alpine {\n", "namespace alpine {\n__device__ unsigned long long g_clk[4 * 1024];\n", 1)
+    for name, a0, a1 in SWEEP_MARKS:
+        k = x.index(name)
+        body = x[k:]
+        assert a0 in body and a1 in body, f"source changed: {name}"
+        body = body.replace(a0, a0 + "    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();\n", 1)
+        body = body.replace(a1, a1 + "        if (tid == 0) { g_clk[4 * (blockIdx.x & 1023)] = __builtin_amdgcn_s_memtime() - clk_t0; "
+                                     "g_clk[4 * (blockIdx.x & 1023) + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }\n", 1)
+        x = x[:k] + body
+    open(xp, "w").write(x)
     hp = os.path.join(work, "alpine_amd", "csrc", "alpine_hip.hip")
     open(hp, "a").write('\nextern "C" int alpine_debug_read_stamps(unsigned long long* host, int n)\n{\n    return (int)hipMemcpyFromSymbol('
-                        'host, HIP_SYMBOL(alpine::g_stamps), sizeof(unsigned long long) * n);\n}\n')
+                        'host, HIP_SYMBOL(alpine::g_stamps), sizeof(unsigned long long) * n);\n}\n'
+                        'extern "C" int alpine_debug_read_clk(unsigned long long* host, int n)\n{\n    return (int)hipMemcpyFromSymbol('
+                        'host, HIP_SYMBOL(alpine::g_clk), sizeof(unsigned long long) * n);\n}\n')
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
                     "-fno-slp-vectorize", "-o", LIB, hp, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     print(LIB)
@@ -101,8 +127,55 @@ def run(cells):
     eng.close()
 
 
+def sweepclock(x_scale):
+    import time
+    os.environ["ALPINE_HIP_LIBRARY"] = LIB
+    sys.path.insert(0, REPO)
+    import torch
+    import bench
+    from alpine_amd import _native
+    from alpine_amd.datasets import synth_counts_device_chunks
+    from alpine_amd.model import draw_initial_factors
+    wl = dict(bench.WORKLOADS["cfg3"])
+    G, N, ku, kcov = wl["genes"], wl["cells"], wl["ku"], wl["kcov"]
+    dev = torch.device("cuda", 0)
+    W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], [2, 2])
+    eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=[2, 2], lam=[1e3, 1e3],
+                              orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype="x3")
+    for off, chunk in synth_counts_device_chunks(N, G, rank=ku, seed=0, device=dev, chunk_cells=8192):
+        if x_scale != 1.0:
+            chunk = (chunk * x_scale).contiguous()
+        torch.cuda.synchronize()
+        eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
+        eng.synchronize()
+    eng.finalize_X()
+    for i in range(2):
+        eng.upload_Y(i, bench.labels_onehot(N, seed=1 + i))
+    eng.set_factors(W0, H0, B0)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 3.0:              # >= 2 s of back-to-back launches before the reading
+        eng.run(50, with_loss=True)
+        eng.synchronize()
+        n += 50
+    info = eng.info()
+    lib = _native.load()
+    nwg = info.grid_b
+    buf = (C.c_ulonglong * (4 * 1024))()
+    lib.alpine_debug_read_clk.argtypes = [C.c_void_p, C.c_int]
+    assert lib.alpine_debug_read_clk(buf, 4 * 1024) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4)[:nwg, :2].astype(np.float64)
+    ghz = a[:, 0] / a[:, 1] * 0.1
+    print(f"x_scale {x_scale}: x3_wide={info.x3_wide} multi-plane fraction {info.x_multi_plane_fraction:.3f}; {n} iterations in "
+          f"{time.perf_counter() - t0:.1f} s; last W^TX sweep: {nwg} workgroups, in-kernel clock median {np.median(ghz):.3f} GHz "
+          f"(p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}); workgroup lifetime median {np.median(a[:, 1]) / 100.0:.1f} us")
+    eng.close()
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "build":
+    if len(sys.argv) > 1 and sys.argv[1] == "sweepclock":
+        sweepclock(float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "build":
         build()
     elif len(sys.argv) > 1 and sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 25000)
