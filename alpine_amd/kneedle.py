@@ -15,8 +15,12 @@ ICDCS-W 2011) in the form kneed 0.8 implements it (offline mode, sensitivity S =
   6. walk the curve from the first candidate; the first point where d drops below the current threshold confirms
      the candidate -> elbow = x[candidate].
 
-PARITY UNPINNED: neither the reference's tests (it has none) nor anything runnable here (kneed is absent, nothing may
-be installed) pins the elbow index this returns against kneed's; tests cover its invariants only.
+PARITY UNPINNED against kneed for the reference's configuration: neither the reference's tests (it has none) nor anything
+runnable here (kneed is absent, nothing may be installed) pins the elbow index this returns against kneed's.  What IS
+pinned is the core of the algorithm (steps 2, 4-6) by the worked example of the Kneedle manuscript itself (its Figure 2:
+y = -1/(x + 0.1) + 5 on ten points of [0, 1], concave and increasing, S = 1 -> knee at x = 0.22):
+``find_knee(x, y, curve="concave", direction="increasing")`` returns 0.2222 (tests/test_host_api.py); the rest of the
+tests cover invariants.
 """
 from __future__ import annotations
 
@@ -35,20 +39,8 @@ def _local_extrema(d: np.ndarray, greater: bool) -> np.ndarray:
     return np.flatnonzero(mask)
 
 
-def find_elbow(x, y, S: float = 1.0, polynomial_degree: int = 2) -> Optional[float]:
-    """Elbow of a convex, decreasing curve; returns the x value or None if no knee is found."""
-    x = np.asarray(x, dtype=np.float64)
-    y = np.asarray(y, dtype=np.float64)
-    if len(x) < 3 or not np.all(np.isfinite(y)):
-        return None
-    ds_y = np.poly1d(np.polyfit(x, y, polynomial_degree))(x)
-    span_x, span_y = x.max() - x.min(), ds_y.max() - ds_y.min()
-    if span_x == 0 or span_y == 0:
-        return None
-    xn = (x - x.min()) / span_x
-    yn = (ds_y - ds_y.min()) / span_y
-    yn = yn.max() - yn                                  # convex + decreasing -> knee form
-    d = yn - xn
+def _kneedle_walk(x: np.ndarray, xn: np.ndarray, d: np.ndarray, S: float) -> Optional[float]:
+    """Steps 4-6 on a difference curve d over normalised abscissae xn (knee form: concave, increasing)."""
     maxima = _local_extrema(d, greater=True)
     minima = _local_extrema(d, greater=False)
     if maxima.size == 0:
@@ -69,3 +61,37 @@ def find_elbow(x, y, S: float = 1.0, polynomial_degree: int = 2) -> Optional[flo
         if d[i + 1] < threshold:
             return float(x[threshold_index])
     return None
+
+
+def find_knee(x, y, curve: str = "concave", direction: str = "increasing", S: float = 1.0,
+              polynomial_degree: Optional[int] = None) -> Optional[float]:
+    """Knee / elbow of a curve in the four (curve, direction) forms of the Kneedle manuscript; ``polynomial_degree`` = None
+    uses the points as they are (the manuscript's worked example), an integer smooths with a least-squares polynomial."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if len(x) < 3 or not np.all(np.isfinite(y)):
+        return None
+    ds_y = y if polynomial_degree is None else np.poly1d(np.polyfit(x, y, polynomial_degree))(x)
+    span_x, span_y = x.max() - x.min(), ds_y.max() - ds_y.min()
+    if span_x == 0 or span_y == 0:
+        return None
+    xn = (x - x.min()) / span_x
+    yn = (ds_y - ds_y.min()) / span_y
+    # bring every form to the knee form (concave, increasing), as kneed's transform_y does
+    if curve == "convex" and direction == "decreasing":
+        yn = yn.max() - yn
+    elif curve == "convex" and direction == "increasing":
+        xn_, yn_ = xn.max() - xn[::-1], yn.max() - yn[::-1]
+        knee = _kneedle_walk(x[::-1], xn_, yn_ - xn_, S)
+        return knee
+    elif curve == "concave" and direction == "decreasing":
+        xn_, yn_ = xn.max() - xn[::-1], yn[::-1]
+        return _kneedle_walk(x[::-1], xn_, yn_ - xn_, S)
+    elif not (curve == "concave" and direction == "increasing"):
+        raise ValueError("curve must be 'concave' or 'convex', direction 'increasing' or 'decreasing'")
+    return _kneedle_walk(x, xn, yn - xn, S)
+
+
+def find_elbow(x, y, S: float = 1.0, polynomial_degree: int = 2) -> Optional[float]:
+    """Elbow of a convex, decreasing curve (the reference's call, main.py:758-765); returns the x value or None."""
+    return find_knee(x, y, curve="convex", direction="decreasing", S=S, polynomial_degree=polynomial_degree)

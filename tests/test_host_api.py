@@ -229,6 +229,20 @@ def test_synthetic_generator_is_count_like():
     assert lab.dtype.kind == "O" and set(lab) <= {"a", "b"}
 
 
+def test_kneedle_core_reproduces_the_manuscripts_worked_example():
+    """Figure 2 of the Kneedle manuscript (Satopaa et al., ICDCS-W 2011): y = -1/(x + 0.1) + 5 on ten points of [0, 1] is concave
+    and increasing, and with sensitivity S = 1 the algorithm places its knee at x = 0.22.  The difference-curve / threshold
+    walk of alpine_amd.kneedle must land on exactly that point (x[2] = 0.2222)."""
+    from alpine_amd.kneedle import find_knee
+    x = np.linspace(0.0, 1.0, 10)
+    y = -1.0 / (x + 0.1) + 5.0
+    knee = find_knee(x, y, curve="concave", direction="increasing", S=1.0)
+    assert knee == pytest.approx(2.0 / 9.0, abs=1e-12) and round(knee, 2) == 0.22
+    # the mirrored forms of the same curve find the mirrored point
+    assert find_knee(x, y.max() - y, curve="convex", direction="decreasing", S=1.0) == pytest.approx(2.0 / 9.0, abs=1e-12)
+    assert find_knee(-x[::-1], y[::-1], curve="concave", direction="decreasing", S=1.0) == pytest.approx(-2.0 / 9.0, abs=1e-12)
+
+
 def test_kneedle_restatement_invariants():
     """alpine_amd.kneedle (fallback for the absent `kneed`, parity unpinned): invariants of the published algorithm."""
     from alpine_amd.kneedle import find_elbow
