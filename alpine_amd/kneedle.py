@@ -19,8 +19,10 @@ PARITY UNPINNED against kneed for the reference's configuration: neither the ref
 runnable here (kneed is absent, nothing may be installed) pins the elbow index this returns against kneed's.  What IS
 pinned is the core of the algorithm (steps 2, 4-6) by the worked example of the Kneedle manuscript itself (its Figure 2:
 y = -1/(x + 0.1) + 5 on ten points of [0, 1], concave and increasing, S = 1 -> knee at x = 0.22):
-``find_knee(x, y, curve="concave", direction="increasing")`` returns 0.2222 (tests/test_host_api.py); the rest of the
-tests cover invariants.
+``find_knee(x, y, curve="concave", direction="increasing")`` returns 0.2222 (tests/test_host_api.py), and the four
+(curve, direction) transforms by the ten-point sample curves of kneed's own DataGenerator with the knees its test-suite
+states for them (2, 7, 7, 2; written down from the published tests, kneed itself cannot run here); the rest of the tests
+cover invariants.
 """
 from __future__ import annotations
 

@@ -243,6 +243,25 @@ def test_kneedle_core_reproduces_the_manuscripts_worked_example():
     assert find_knee(-x[::-1], y[::-1], curve="concave", direction="decreasing", S=1.0) == pytest.approx(-2.0 / 9.0, abs=1e-12)
 
 
+@pytest.mark.parametrize("curve,direction,y,knee", [
+    ("convex", "increasing", [1, 2, 3, 4, 5, 10, 15, 20, 40, 100], 7),
+    ("convex", "decreasing", [100, 40, 20, 15, 10, 5, 4, 3, 2, 1], 2),
+    ("concave", "decreasing", [99, 98, 97, 96, 95, 90, 85, 80, 60, 0], 7),
+    ("concave", "increasing", [0, 60, 80, 85, 90, 95, 96, 97, 98, 99], 2),
+])
+def test_kneedle_four_curve_forms_on_kneeds_sample_curves(curve, direction, y, knee):
+    """The four ten-point sample curves of the `kneed` package's DataGenerator (convex/concave x increasing/decreasing over
+    x = 0..9) with the knees its test-suite expects for them (2, 7, 7, 2), for both interpolation forms it is parametrised
+    over (the points as they are; a polynomial fit, degree 7 = kneed's default).  `kneed` is absent from this image and
+    from the reference tree, so the vectors are written down from the package's published tests, not generated here:
+    they pin the transform of each (curve, direction) form onto the knee form, which the manuscript's single example
+    does not."""
+    from alpine_amd.kneedle import find_knee
+    x = np.arange(10)
+    assert find_knee(x, y, curve=curve, direction=direction) == knee
+    assert find_knee(x, y, curve=curve, direction=direction, polynomial_degree=7) == knee
+
+
 def test_kneedle_restatement_invariants():
     """alpine_amd.kneedle (fallback for the absent `kneed`, parity unpinned): invariants of the published algorithm."""
     from alpine_amd.kneedle import find_elbow
