@@ -1277,6 +1277,8 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
     if (rc) return rc;
     if (c->transform_only || c->bf16) return fail(c, ALPINE_ERR_UNSUPPORTED, "mini-batches need the float32 two-copy layout");
     if (c->batch_open) return fail(c, ALPINE_ERR_STATE, "alpine_batch_begin: the previous batch was not ended");
+    if (c->use_als && c->comm_ranks > 1)
+        return fail(c, ALPINE_ERR_UNSUPPORTED, "mini-batches with ALPINE_FLAG_USE_ALS are single-shard (the group loop of a batch has no exchange step)");
     if (n < 0 || n > c->batch_cap || (n > 0 && !idx))
         return fail(c, ALPINE_ERR_BAD_ARG, "batch of %lld cells outside the ctx's batch_capacity %lld", (long long)n, (long long)c->batch_cap);
     c->batch_n = n;

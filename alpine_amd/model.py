@@ -554,7 +554,8 @@ class ALPINE:
         (sampling.py:18-33).  Each batch is one alpine_batch_step; one loss row over all cells per epoch.
         Sharded (``comm``): every rank draws the SAME global index stream (same seed), takes the indices that fall into
         its block [c0, c1) -- possibly none -- and the reduce block is all-reduced between alpine_batch_begin and
-        alpine_batch_end (and between the two halves of the epoch loss)."""
+        alpine_batch_end (and between the two halves of the epoch loss); with the library's own communicator attached
+        alpine_batch_step / alpine_epoch_loss do all three steps in C."""
         self._rng_replay = None                                     # the stream is consumed for real here
         weights = None
         if self.sampling_method == "weighted":
@@ -566,6 +567,8 @@ class ALPINE:
             weights = torch.as_tensor(self._balanced_joint_weights(Y_all), dtype=torch.double)
         bs = self.batch_size
         c1 = n_total if c1 is None else c1
+        # the library's own communicator: alpine_batch_step / alpine_epoch_loss enqueue the all-reduce themselves
+        composite = bool(getattr(comm, "native", False))
         for _ in range(n_iter):
             if weights is not None:
                 epoch = torch.multinomial(weights, n_total, True).numpy()
@@ -575,11 +578,13 @@ class ALPINE:
                 batch = epoch[b0:min(b0 + bs, n_total)]
                 if comm is None:
                     eng.batch_step(batch)
+                elif composite:
+                    eng.batch_step(batch[(batch >= c0) & (batch < c1)] - c0)
                 else:
                     eng.batch_begin(batch[(batch >= c0) & (batch < c1)] - c0)
                     comm.all_reduce()
                     eng.batch_end()
-            if comm is None:
+            if comm is None or composite:
                 eng.epoch_loss()
             else:
                 eng.epoch_loss_begin()

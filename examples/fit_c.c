@@ -192,11 +192,15 @@ int main(int argc, char** argv)
     char idp[4096];
     snprintf(idp, sizeof idp, "%s.id", argv[4]);
     remove(idp);                                           /* a stale id of an earlier run must not be picked up */
+    /* rank r runs on device r % D; D = R unless FIT_C_DEVICE_COUNT says otherwise (RCCL itself wants one device per rank:
+     * fewer devices than ranks is for tests that preload a stand-in communicator on a one-GPU machine) */
+    const char* dc = getenv("FIT_C_DEVICE_COUNT");
+    const int D = dc && atoi(dc) >= 1 ? atoi(dc) : R;
     pid_t pids[64];
     for (int r = 0; r < R; ++r) {                          /* fork BEFORE any GPU call: the parent never touches the device */
         pids[r] = fork();
         if (pids[r] < 0) { perror("fork"); return 2; }
-        if (pids[r] == 0) _exit(run_shard(argv[3], argv[4], r, R, r));
+        if (pids[r] == 0) _exit(run_shard(argv[3], argv[4], r, R, r % D));
     }
     int bad = 0;
     for (int r = 0; r < R; ++r) {

@@ -1,0 +1,117 @@
+"""The library's NATIVE multi-rank loop with more than one rank, on a one-GPU box.
+
+RCCL refuses two ranks on one device, so on this pool the communicator inside libalpine_hip.so could otherwise only run at
+world size 1 (tests/test_gpu_nccl.py), where every all-reduce is the identity.  Here the rank processes are started with
+tests/stub_rccl/rccl_stub.cpp preloaded: a shared-memory stand-in for the five RCCL entry points the library calls (its own
+CPU check: tests/test_comm_stub_selftest.py).  Everything above those five calls is the product path, unchanged: the same
+libalpine_hip.so, `alpine_comm_init_rank`, and the C loops of `alpine_run` / `alpine_iter` / `alpine_batch_step` /
+`alpine_epoch_loss` that decide which slot of the reduce block is exchanged when.  Two ranks share cuda:0; results must
+equal the single-device run to rounding and the reference's golden vectors to the stated tolerance.
+
+What this does NOT show: anything about RCCL or xGMI (bandwidth, stream ordering inside RCCL) -- see DESIGN.md 5."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from _golden import assert_loss_rows_close, load_case, rel_fro
+from _stub import build_rccl_stub
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class preload_stub:
+    """LD_PRELOAD for the processes started inside the block (spawned children inherit the environment at exec)."""
+
+    def __enter__(self):
+        self.old = os.environ.get("LD_PRELOAD")
+        lib = build_rccl_stub()
+        os.environ["LD_PRELOAD"] = lib if not self.old else lib + ":" + self.old
+        return lib
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("LD_PRELOAD", None)
+        else:
+            os.environ["LD_PRELOAD"] = self.old
+        return False
+
+
+def _spawn(case_name, tmp_path, local):
+    import torch.multiprocessing as mp
+    from test_gpu_sharded import _free_port, _worker
+    world = 2
+    with preload_stub():
+        mp.spawn(_worker, args=(world, _free_port(), case_name, str(tmp_path), local, "native"), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(world)]
+    assert all(str(x["comm"]) == "native" for x in r)          # the library's own communicator carried every exchange
+    assert np.array_equal(r[0]["W"], r[1]["W"]) and np.array_equal(r[0]["losses"], r[1]["losses"])
+    return r
+
+
+def _check_against_golden(c, r, local):
+    H = np.concatenate([r[0]["H"], r[1]["H"]], axis=1) if local else r[0]["H"]
+    assert rel_fro(r[0]["W"], c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
+    for i, bt in enumerate(c.BT):
+        assert rel_fro(r[0][f"B{i}"], bt) < 2e-4
+    assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
+    return H
+
+
+@pytest.mark.parametrize("case_name,local", [("kl_2cov_nan", False), ("counts_2cov", True), ("fro_2cov_reg", False)])
+def test_native_loop_two_ranks_full_batch(case_name, local, tmp_path):
+    """alpine_run with a two-rank communicator: one exchange of the whole reduce block per iteration (+ one for the last
+    loss row).  Equal to the single-device run up to the summation order of the two shards."""
+    from alpine_amd import ALPINE, MiniAnnData
+    r = _spawn(case_name, tmp_path, local)
+    c = load_case(case_name)
+    H = _check_against_golden(c, r, local)
+    single = ALPINE(device="cuda:0", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
+    assert rel_fro(r[0]["W"], np.concatenate(single.matrices["Ws"], axis=1)) < 2e-5
+    assert rel_fro(H, np.concatenate(single.matrices["Hs"], axis=0)) < 2e-5
+
+
+@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True)])
+def test_native_loop_two_ranks_block_coordinate(case_name, local, tmp_path):
+    """use_als: alpine_iter exchanges the K x K H H^T slot after every component group, in C."""
+    r = _spawn(case_name, tmp_path, local)
+    c = load_case(case_name)
+    assert c.params.get("use_als")
+    _check_against_golden(c, r, local)
+
+
+@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", True), ("weighted_skew", False)])
+def test_native_loop_two_ranks_minibatch(case_name, local, tmp_path):
+    """Mini-batches: alpine_batch_step (gather, phase 1, exchange, phase 2, scatter) and alpine_epoch_loss with the
+    communicator attached, including batches of which a rank holds no cell (weighted_skew: most draws fall into rank 0's
+    block)."""
+    r = _spawn(case_name, tmp_path, local)
+    _check_against_golden(load_case(case_name), r, local)
+
+
+@pytest.mark.parametrize("name", ["kl_2cov_nan", "als_kl"])
+def test_c_host_two_ranks(name, tmp_path):
+    """examples/fit_c --ranks 2: a plain-C host forks two rank processes, passes the communicator id through a file and
+    splices the ranks' H blocks; no Python and no torch in those processes."""
+    from test_c_abi_example import build_example, read_result, write_problem
+    exe = build_example()
+    c = load_case(name)
+    flags = 16 | (4 if c.params.get("use_als") else 0)
+    prob, res1, res2 = tmp_path / "p.bin", tmp_path / "r1.bin", tmp_path / "r2.bin"
+    write_problem(prob, c, flags)
+    r = subprocess.run([exe, str(prob), str(res1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with preload_stub():
+        r = subprocess.run([exe, "--ranks", "2", str(prob), str(res2)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, FIT_C_DEVICE_COUNT="1"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    l1, W1, H1, _ = read_result(res1, c)
+    l2, W2, H2, Bs = read_result(res2, c)
+    assert rel_fro(W2, W1) < 2e-5 and rel_fro(H2, H1) < 2e-5
+    assert rel_fro(W2, c.WT) < 1e-4 and rel_fro(H2, c.HT) < 1e-4
+    for b, bt in zip(Bs, c.BT):
+        assert rel_fro(b, bt) < 2e-4
+    assert_loss_rows_close(l2, c.loss_history, n_cells=c.X.shape[0])

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, out_dir, local=False):
+def _worker(rank, world, port, case_name, out_dir, local=False, shard_comm="auto"):
     # (fit_kwargs of the golden case -- batch_size / sampling_method -- are passed through: sharded mini-batches)
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -37,7 +37,7 @@ def _worker(rank, world, port, case_name, out_dir, local=False):
         n = c.X.shape[0]
         cut = [0, n // 3 + 1, n]
         adata = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
-        m = ALPINE(device="cuda:0", shard_cells="local", **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+        m = ALPINE(device="cuda:0", shard_cells="local", shard_comm=shard_comm, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
         assert adata.obsm["ALPINE_embedding"].shape[0] == cut[rank + 1] - cut[rank]
         if c.transform_iters:                      # transform of the rank's own cells right after the fit
             a_t = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
@@ -46,9 +46,9 @@ def _worker(rank, world, port, case_name, out_dir, local=False):
                     np.concatenate([np.asarray(a_t.obsm[k]).T for k in c.keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0))
     else:
         adata = MiniAnnData(c.X.copy(), c.obs.copy())
-        m = ALPINE(device="cuda:0", shard_cells=True, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+        m = ALPINE(device="cuda:0", shard_cells=True, shard_comm=shard_comm, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=np.concatenate(m.matrices["Ws"], axis=1),
-             H=np.concatenate(m.matrices["Hs"], axis=0), losses=m.loss_history.to_numpy(),
+             H=np.concatenate(m.matrices["Hs"], axis=0), losses=m.loss_history.to_numpy(), comm=np.array(m.shard_comm_used),
              **{f"B{i}": b for i, b in enumerate(m.matrices["Bs"])})
     dist.barrier()
     dist.destroy_process_group()
