@@ -115,3 +115,24 @@ def test_c_host_two_ranks(name, tmp_path):
     for b, bt in zip(Bs, c.BT):
         assert rel_fro(b, bt) < 2e-4
     assert_loss_rows_close(l2, c.loss_history, n_cells=c.X.shape[0])
+
+
+def test_bench_two_ranks_native_carrier():
+    """`python bench.py --gpus 2 --comm native` as the driver's N > 1 runs use it (own launcher, the library's communicator,
+    the all-reduce timed by the library's events), rehearsed on one GPU with the stand-in carrying the bytes."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ALPINE_BENCH_REHEARSAL_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--comm", "native", "--workload", "tiny", "--steps", "4", "--warmup", "1"]
+    with preload_stub() as lib:
+        env["LD_PRELOAD"] = lib
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    ar = d["allreduce"]
+    assert ar["carrier"].startswith("native") and ar["fallback_note"] is None
+    assert ar["avg_ms_on_rank0"] > 0 and ar["bytes"] > 0

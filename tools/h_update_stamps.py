@@ -50,7 +50,11 @@ PHASES = ["Y / 2W^TW / B fills + barrier", "H issue + pieces + H to C/D", "2W^TW
           "barrier + H H^T partial", "covariate statistics"]
 
 
-def build():
+def build(wxor=0):
+    """wxor != 0: the sweep workgroups take the work range of blockIdx ^ wxor (same results; moves every range to another XCD)."""
+    global LIB
+    if wxor:
+        LIB = LIB.replace(".so", f"_x{wxor}.so")
     work = "/tmp/alpine_stamp_build"
     shutil.rmtree(work, ignore_errors=True)
     os.makedirs(os.path.join(work, "alpine_amd"))
@@ -74,9 +78,15 @@ def build():
         k = x.index(name)
         body = x[k:]
         assert a0 in body and a1 in body, f"source changed: {name}"
+        if wxor:
+            assert "    const int w = blockIdx.x;\n" in body
+            body = body.replace("    const int w = blockIdx.x;\n", f"    const int w = blockIdx.x ^ {wxor};\n", 1)
         body = body.replace(a0, a0 + "    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();\n", 1)
         body = body.replace(a1, a1 + "        if (tid == 0) { g_clk[4 * (blockIdx.x & 1023)] = __builtin_amdgcn_s_memtime() - clk_t0; "
-                                     "g_clk[4 * (blockIdx.x & 1023) + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }\n", 1)
+                                     "const unsigned long long clk_r1 = __builtin_amdgcn_s_memrealtime(); "
+                                     "g_clk[4 * (blockIdx.x & 1023) + 1] = clk_r1 - clk_r0; g_clk[4 * (blockIdx.x & 1023) + 2] = clk_r0; "
+                                     "unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc)); "
+                                     "g_clk[4 * (blockIdx.x & 1023) + 3] = (unsigned long long)(xcc & 15u); }\n", 1)
         x = x[:k] + body
     open(xp, "w").write(x)
     hp = os.path.join(work, "alpine_amd", "csrc", "alpine_hip.hip")
@@ -127,9 +137,9 @@ def run(cells):
     eng.close()
 
 
-def sweepclock(x_scale):
+def sweepclock(x_scale, wxor=0):
     import time
-    os.environ["ALPINE_HIP_LIBRARY"] = LIB
+    os.environ["ALPINE_HIP_LIBRARY"] = LIB.replace(".so", f"_x{wxor}.so") if wxor else LIB
     sys.path.insert(0, REPO)
     import torch
     import bench
@@ -164,8 +174,24 @@ def sweepclock(x_scale):
     buf = (C.c_ulonglong * (4 * 1024))()
     lib.alpine_debug_read_clk.argtypes = [C.c_void_p, C.c_int]
     assert lib.alpine_debug_read_clk(buf, 4 * 1024) == 0
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4)[:nwg, :2].astype(np.float64)
+    raw = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4)[:nwg]
+    a = raw[:, :2].astype(np.float64)
     ghz = a[:, 0] / a[:, 1] * 0.1
+    # spread of the workgroups of that launch on the shared 100 MHz counter: who starts late, who ends late, by XCD
+    start = (raw[:, 2] - raw[:, 2].min()).astype(np.float64) / 100.0
+    life = a[:, 1] / 100.0
+    end = start + life
+    xcc = raw[:, 3].astype(np.int64)
+    pc = lambda v: " / ".join(f"{np.percentile(v, q):.1f}" for q in (0, 10, 50, 90, 100))
+    print(f"  start offsets us (min/p10/p50/p90/max): {pc(start)}")
+    print(f"  lifetimes us: {pc(life)}")
+    print(f"  end offsets us: {pc(end)}   -> span first start .. last end {end.max():.1f} us; work-balanced ideal {life.mean() + start.min():.1f} us")
+    for x in sorted(set(xcc.tolist())):
+        m = xcc == x
+        print(f"  XCD {x}: {int(m.sum())} workgroups, lifetime median {np.median(life[m]):.1f} us (min {life[m].min():.1f}, max {life[m].max():.1f}), start median {np.median(start[m]):.1f}")
+    order = np.argsort(life)
+    print("  slowest 8 workgroups (blockIdx, XCD, lifetime us):", [(int(i), int(xcc[i]), round(float(life[i]), 1)) for i in order[-8:]])
+    print("  fastest 8 workgroups:", [(int(i), int(xcc[i]), round(float(life[i]), 1)) for i in order[:8]])
     print(f"x_scale {x_scale}: x3_wide={info.x3_wide} multi-plane fraction {info.x_multi_plane_fraction:.3f}; {n} iterations in "
           f"{time.perf_counter() - t0:.1f} s; last W^TX sweep: {nwg} workgroups, in-kernel clock median {np.median(ghz):.3f} GHz "
           f"(p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}); workgroup lifetime median {np.median(a[:, 1]) / 100.0:.1f} us")
@@ -174,9 +200,9 @@ def sweepclock(x_scale):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sweepclock":
-        sweepclock(float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
+        sweepclock(float(sys.argv[2]) if len(sys.argv) > 2 else 1.0, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "build":
-        build()
+        build(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 25000)
     else:
