@@ -65,6 +65,22 @@ def test_product_package_does_not_import_oracle():
                 assert not any(n.split(".")[0] == "oracle" for n in names), f"{fn} imports the oracle"
 
 
+def test_product_never_refers_to_the_test_stand_in_for_rccl():
+    """tests/stub_rccl is test infrastructure: no source of the package, the bench, the entry point or the examples names it,
+    and the shipped library needs the real librccl.so.1."""
+    srcs = [os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py")]
+    for root in ("alpine_amd", "examples", "include"):
+        for dp, _, fns in os.walk(os.path.join(REPO, root)):
+            srcs += [os.path.join(dp, f) for f in fns if f.endswith((".py", ".hip", ".hpp", ".h", ".c"))]
+    for path in srcs:
+        text = open(path, errors="replace").read()
+        assert "rccl_stub" not in text and "stub_rccl" not in text, path
+    import subprocess
+    from alpine_amd.build import build_library
+    needed = subprocess.run(["readelf", "-d", build_library()], capture_output=True, text=True, check=True).stdout
+    assert "librccl.so.1" in needed and "stub" not in needed
+
+
 @pytest.mark.parametrize("name", ALL_CASES)
 def test_initial_draws_match_reference_bitwise(name):
     from alpine_amd.model import draw_initial_factors
