@@ -136,3 +136,44 @@ def test_bench_two_ranks_native_carrier():
     ar = d["allreduce"]
     assert ar["carrier"].startswith("native") and ar["fallback_note"] is None
     assert ar["avg_ms_on_rank0"] > 0 and ar["bytes"] > 0
+
+
+def _als_minibatch_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alpine_amd import _native
+    from alpine_amd.sharded import attach_native_comm
+    rng = np.random.default_rng(3)
+    eng = _native.NativeShard(n_genes=40, n_cells=64, n_components=3, cov_components=[2], cov_levels=[2], lam=[1.0], use_als=True,
+                              batch_capacity=32, x_dtype="x3")
+    eng.upload_X_host(rng.random((64, 40), dtype=np.float32))
+    eng.finalize_X()
+    eng.upload_Y(0, np.eye(2, dtype=np.float32)[rng.integers(0, 2, size=64)].T.copy())
+    eng.set_factors(rng.random((40, 5), dtype=np.float32), rng.random((5, 64), dtype=np.float32), [rng.random((2, 2), dtype=np.float32)])
+    attach_native_comm(eng, dist)
+    try:
+        eng.batch_step(np.arange(16))
+        msg = "no error"
+    except _native.AlpineNativeError as e:
+        msg = f"{e.code}: {e}"
+    eng.close()
+    open(os.path.join(out_dir, f"als_mb_rank{rank}.txt"), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_als_minibatch_is_refused_on_a_two_rank_communicator(tmp_path):
+    """The group loop of a mini-batch step has no exchange point, so with more than one rank it would silently use local
+    sums: alpine_batch_begin must say ALPINE_ERR_UNSUPPORTED (-5) instead -- on every rank, before any collective."""
+    import torch.multiprocessing as mp
+    from test_gpu_sharded import _free_port
+    with preload_stub():
+        mp.spawn(_als_minibatch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg = open(tmp_path / f"als_mb_rank{r}.txt").read()
+        assert msg.startswith("-5:") and "single-shard" in msg, msg
