@@ -5,7 +5,7 @@ run in FLOAT64 on the host from the same initial factors (the float32 CPU oracle
 Not collected by pytest (32 GB of float64 X on the host, ~1e12 flops per float64 iteration): the committed full-size
 tests check size-independent properties instead (tests/test_gpu_fullsize.py).  Usage:
 
-    python tests/fullsize_vs_float64.py [--iters 3] [--cells 200000] [--x-scale 1.0] [--out file.json]
+    python tests/fullsize_vs_float64.py [--workload cfg3] [--iters 3] [--cells N] [--x-scale 1.0] [--out file.json]
 
 Prints and writes: relative Frobenius error of W, H and every B_i after `iters` iterations, and the loss rows against the
 float64 run's own rows."""
@@ -29,14 +29,15 @@ from oracle import alpine_oracle as orc            # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=3)
-    ap.add_argument("--cells", type=int, default=200000)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--cells", type=int, default=0, help="0 = the workload's own (cfg4: 1 000 000 -- pass its per-GPU share, 125000)")
     ap.add_argument("--x-scale", type=float, default=1.0)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     from alpine_amd import _native
     from alpine_amd.datasets import synth_counts_device_chunks
-    wl = dict(bench.WORKLOADS["cfg3"])
-    G, N, ku, kcov = wl["genes"], a.cells, wl["ku"], wl["kcov"]
+    wl = dict(bench.WORKLOADS[a.workload])
+    G, N, ku, kcov = wl["genes"], a.cells or wl["cells"], wl["ku"], wl["kcov"]
     levels, lam = [2] * len(kcov), [1e3] * len(kcov)
     dev = torch.device("cuda", 0)
     p = orc.OracleParams(n_components=ku, n_covariate_components=kcov, lam=lam, orth_W=wl["orth_W"], alpha_W=wl["alpha_W"],
@@ -55,7 +56,7 @@ def main():
     s32 = orc.init_factors(p, np.ascontiguousarray(X.T), [y.T for y in Ys])
     W0, H0, B0 = s32.W.numpy().copy(), s32.H.numpy().copy(), [b.numpy().copy() for b in s32.Bs]
 
-    res = {"workload": f"cfg3: {G} genes x {N} cells, K={ku}+{kcov}, x_scale={a.x_scale}", "iters": a.iters, "modes": {}}
+    res = {"workload": f"{a.workload}: {G} genes x {N} cells, K={ku}+{kcov}, x_scale={a.x_scale}", "iters": a.iters, "modes": {}}
     for mode in ("x3", "f32") + (("split",) if a.x_scale == 1.0 else ()):
         eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
                                   orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype=mode)
