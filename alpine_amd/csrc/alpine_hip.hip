@@ -806,6 +806,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     if (c->x3) {
         SweepGeom gx = g;
         if (c->ablate_flush) gx.panel_fixed = 2;
+        else if (c->ablate_panel) gx.panel_fixed = 1;
         if (c->x3_wide && !c->x3_ablate) {
             const bool pad_tile = c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
 #define X3W_LAUNCH(KT_, NH_) do { \

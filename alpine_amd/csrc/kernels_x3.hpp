@@ -183,8 +183,15 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         // memory; those accumulators land in piece columns >= F, which no consumer reads)
         const int f1 = (NH == 2 && f0 + 128 < g.F) ? f0 + 128 : f0;
 
+#ifdef ALPINE_DIAGNOSTICS
+        const bool pfix = g.panel_fixed == 1;          // timing-only ablation: every panel stage re-reads the first rows of P (cache-resident)
+        const float* pfptr = Pf + (pfix ? (int64_t)0 : (int64_t)r_begin * KP);
+#else
+        constexpr bool pfix = false;
         const float* pfptr = Pf + (int64_t)r_begin * KP;
+#endif
         auto load_p = [&](int t) {
+            if (pfix) t = 0;
 #pragma unroll
             for (int v = 0; v < PVS; ++v) {
                 const int si = tid + NT * v;                        // set index = rb * KP + col
