@@ -315,3 +315,20 @@ def test_covariate_gene_scores_match_reference(name):
     a = MiniAnnData(c.X.copy(), c.obs.copy())
     assert m.get_covariate_gene_scores(a) is None
     assert sorted(a.varm) == ph.varm_keys
+
+
+def test_all_nonnegative_matches_numpy_on_every_layout():
+    """The threaded stand-in for np.all(X >= 0) (main.py:399): negatives and NaN anywhere make it False, for C / Fortran
+    order, views with gaps, small and block-spanning sizes, integer dtypes."""
+    from alpine_amd.model import all_nonnegative
+    rng = np.random.default_rng(0)
+    big = rng.random((9000, 4000), dtype=np.float32)                 # 144 MB: three row blocks
+    for X in (big, np.asfortranarray(big[:4500]), big[::2, ::3], big[:1], big[:0], rng.integers(0, 5, size=(50, 7))):
+        assert all_nonnegative(X) == bool(np.all(X >= 0)) is True
+    for r, c in ((0, 0), (8999, 3999), (4321, 17)):
+        for bad in (-1e-30, np.nan, -np.inf):
+            old = big[r, c]
+            big[r, c] = bad
+            assert all_nonnegative(big) is False and all_nonnegative(big[::2, ::3]) == bool(np.all(big[::2, ::3] >= 0))
+            big[r, c] = old
+    assert all_nonnegative(-rng.integers(1, 5, size=(50, 7))) is False

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cells", type=int, default=50000)
     ap.add_argument("--genes", type=int, default=20000)
+    ap.add_argument("--profile", action="store_true", help="cProfile of one fit(max_iter=50): top host-side entries by cumulative time")
     args = ap.parse_args()
     import torch
     from alpine_amd import ALPINE, MiniAnnData, _native
@@ -62,10 +63,29 @@ def main():
     a = MiniAnnData(X, obs.copy())
     timed("warm-up fit(max_iter=5) [first call: library load, allocator]", lambda: ALPINE(**kw).fit(a, covariate_keys=["cond"], max_iter=5).release())
     timed("fit(max_iter=50)", lambda: ALPINE(**kw).fit(a, covariate_keys=["cond"], max_iter=50).release())
+    if args.profile:
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        ALPINE(**kw).fit(a, covariate_keys=["cond"], max_iter=50).release()
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(18)
+        print(buf.getvalue())
     m = timed("fit(max_iter=None) = 200-iteration warm-up + final run, resident X", lambda: ALPINE(**kw).fit(a, covariate_keys=["cond"], max_iter=None))
     print(json.dumps({"max_iter_chosen": m.max_iter}))
     timed("compute_loss(adata), resident engine", lambda: m.compute_loss(a))
     timed("transform(adata, n_iter=50), resident engine", lambda: m.transform(a, n_iter=50))
+    if args.profile:
+        pr = cProfile.Profile()
+        pr.enable()
+        m.transform(a, n_iter=50)
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(16)
+        print(buf.getvalue())
     m.release()
     m2 = timed("fit(max_iter=50, keep_resident=False)", lambda: ALPINE(keep_resident=False, **kw).fit(a, covariate_keys=["cond"], max_iter=50))
     timed("compute_loss(adata), fresh engine", lambda: m2.compute_loss(a))
