@@ -184,8 +184,8 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         const int f1 = (NH == 2 && f0 + 128 < g.F) ? f0 + 128 : f0;
 
 #ifdef ALPINE_DIAGNOSTICS
-        const bool pfix = g.panel_fixed == 1;          // timing-only ablation: every panel stage re-reads the first rows of P (cache-resident)
-        const float* pfptr = Pf + (pfix ? (int64_t)0 : (int64_t)r_begin * KP);
+        const bool pfix = g.panel_fixed == 1;          // timing-only ablation: every panel stage re-reads the span's FIRST stage (cache-resident,
+        const float* pfptr = Pf + (int64_t)r_begin * KP;   // a different address per workgroup: no hot spot in one L2 channel)
 #else
         constexpr bool pfix = false;
         const float* pfptr = Pf + (int64_t)r_begin * KP;
