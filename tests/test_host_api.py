@@ -332,3 +332,24 @@ def test_all_nonnegative_matches_numpy_on_every_layout():
             assert all_nonnegative(big) is False and all_nonnegative(big[::2, ::3]) == bool(np.all(big[::2, ::3] >= 0))
             big[r, c] = old
     assert all_nonnegative(-rng.integers(1, 5, size=(50, 7))) is False
+
+
+@pytest.mark.parametrize("n,times", [(2, 5), (3, 1), (701, 4), (4096, 3), (50000, 2), (1, 3), (0, 2)])
+def test_replay_randperms_leaves_the_generator_where_torch_randperm_does(n, times):
+    """transform() after fit() must draw the reference's own unseeded H init (main.py:687), so fit()'s skipped
+    randperm(N) calls (sampling.py:14) are replayed lazily -- by stepping the mt19937 state directly.  Bitwise the same
+    generator state and the same next draws as the real calls, from a fresh seed and from the middle of a block."""
+    import torch
+    from alpine_amd.model import replay_randperms
+    for warm in (0, 5, 623, 624, 1000):
+        torch.manual_seed(1234)
+        if warm:
+            torch.rand(warm)
+        s0 = torch.get_rng_state()
+        for _ in range(times):
+            torch.randperm(n)
+        want_state, want_next = torch.get_rng_state(), torch.rand(7)
+        torch.set_rng_state(s0)
+        replay_randperms(n, times)
+        assert torch.equal(torch.get_rng_state(), want_state)
+        assert torch.equal(torch.rand(7), want_next)
