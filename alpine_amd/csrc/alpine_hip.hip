@@ -169,7 +169,20 @@ static bool getenv_is(const char* name, char v) { const char* e = std::getenv(na
 static int dev_alloc(alpine_ctx* c, void** p, size_t bytes, bool zero = true)
 {
     if (bytes == 0) bytes = 16;
-    HIPCHK(c, hipMalloc(p, bytes));
+    {
+        const hipError_t e = hipMalloc(p, bytes);
+        if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+            (void)hipGetLastError();                      // the failed allocation must not surface again at the next check
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            *p = nullptr;
+            return fail(c, ALPINE_ERR_OOM, "device %d is out of memory: %.2f GiB requested on top of the %.2f GiB this ctx already holds (%.2f of %.2f GiB free); "
+                        "the float32 storage keeps TWO copies of X (genes x cells and cells x genes): shard the cell axis over more GPUs, or use the "
+                        "bf16-plane storage (half the bytes) where X allows it", c->device, (double)bytes / 1073741824.0, (double)c->bytes / 1073741824.0,
+                        (double)free_b / 1073741824.0, (double)total_b / 1073741824.0);
+        }
+        HIPCHK(c, e);
+    }
     c->bytes += bytes;
     if (zero) HIPCHK(c, hipMemsetAsync(*p, 0, bytes, c->stream));
     return 0;

@@ -859,3 +859,17 @@ def test_x3_tile_width_forms_agree_with_the_reference(name, monkeypatch):
         assert rel_fro(W, c.WT_unscaled) < 1e-4 and rel_fro(H, c.HT_unscaled) < 1e-4, (name, narrow)
         assert_loss_rows_close(res[narrow][1], c.loss_history, n_cells=c.X.shape[0])
     assert rel_fro(res["1"][0][0], res["0"][0][0]) < 2e-5 and rel_fro(res["1"][0][1], res["0"][0][1]) < 2e-5
+
+
+def test_out_of_memory_is_reported_as_such_and_leaves_the_device_usable():
+    """A shard whose two float32 copies of X cannot fit (20 000 x 4 000 000: 2 x 320 GB): alpine_create says ALPINE_ERR_OOM
+    (-3) with the sizes and what to do, frees what it had taken, and the next ctx works."""
+    from alpine_amd import _native as nat
+    with pytest.raises(nat.AlpineNativeError) as e:
+        nat.NativeShard(n_genes=20000, n_cells=4_000_000, n_components=50, cov_components=[5], cov_levels=[2], lam=[1.0], x_dtype="x3")
+    assert e.value.code == -3 and "out of memory" in str(e.value) and "shard the cell axis" in str(e.value)
+    c = load_case("kl_1cov")
+    eng = make_engine(c, x_dtype="x3")
+    eng.run(2, with_loss=True)
+    assert np.isfinite(eng.losses()).all()
+    eng.close()
