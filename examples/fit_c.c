@@ -189,6 +189,7 @@ int main(int argc, char** argv)
         return 2;
     }
     const int R = atoi(argv[2]);
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);          /* RCCL's cross-process handles need dmabuf IPC; read when the HIP runtime starts */
     char idp[4096];
     snprintf(idp, sizeof idp, "%s.id", argv[4]);
     remove(idp);                                           /* a stale id of an earlier run must not be picked up */
