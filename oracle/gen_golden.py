@@ -149,6 +149,24 @@ CASES = [
     dict(name="als_k74_mb", n_cells=300, n_genes=150, seed=15, T=6, fit_kwargs=dict(batch_size=128),
          covariates=[("cond", ["a", "b", "c"], 0.0)],
          params=dict(n_components=70, n_covariate_components=[4], lam=[1e3], use_als=True, orth_W=0.05)),
+    # round 2: paths that only the oracle had covered so far, pinned on the reference itself
+    # more label levels in total (36 + 7 = 43) than the H update keeps in LDS (32): guided terms and statistics read Y from memory
+    dict(name="many_levels", transform_iters=10, n_cells=260, n_genes=90, seed=21, T=12,
+         covariates=[("celltype", [f"t{i:02d}" for i in range(36)], 0.05), ("batch", [f"b{i}" for i in range(7)], 0.0)],
+         params=dict(n_components=6, n_covariate_components=[4, 2], lam=[1e3, 2e2])),
+    # three covariates, Frobenius loss, missing labels, all regularisers
+    dict(name="fro_3cov", n_cells=200, n_genes=96, seed=22, T=20,
+         covariates=[("c1", ["x", "y", "z"], 0.1), ("c2", ["p", "q"], 0.05), ("c3", ["u", "v", "w", "s"], 0.0)],
+         params=dict(n_components=6, n_covariate_components=[2, 3, 2], lam=[5.0, 2.0, 8.0],
+                     loss_type="frobenius", orth_W=0.05, alpha_W=0.2, l1_ratio_W=0.5)),
+    # several workgroup tiles in both sweeps, multi-piece tiles, 12 blocks of 128 cells in the fused tails: counts, K = 47
+    dict(name="mid_counts", transform_iters=8, n_cells=1500, n_genes=700, seed=23, T=12, data="counts",
+         covariates=[("cond", ["a", "b", "c"], 0.02), ("batch", ["b0", "b1"], 0.0)],
+         params=dict(n_components=40, n_covariate_components=[4, 3], lam=[1e3, 5e2], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5)),
+    # block-coordinate branch on weighted mini-batches (duplicates under replacement inside the group loop)
+    dict(name="als_weighted_mb", n_cells=160, n_genes=72, seed=24, T=6, fit_kwargs=dict(batch_size=48, sampling_method="weighted"),
+         covariates=[("c1", ["x", "y", "z"], 0.0), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=5, n_covariate_components=[2, 3], lam=[1e3, 5e2], use_als=True, orth_W=0.05, alpha_W=0.3, l1_ratio_W=0.5)),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,
