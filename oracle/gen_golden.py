@@ -256,7 +256,7 @@ def run_case(case: dict, AnnData, out_dir: str):
           f"loss[-1]={out['loss_history'][-1].tolist()}")
 
 
-POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov"]
+POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov", "many_levels", "fro_3cov"]
 
 
 def run_posthoc(case: dict, AnnData, out_dir: str):

@@ -59,7 +59,7 @@ def load_case(name: str) -> SimpleNamespace:
     return c
 
 
-POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov"]
+POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov", "many_levels", "fro_3cov"]
 
 
 def load_posthoc(name: str) -> SimpleNamespace:
