@@ -167,6 +167,11 @@ CASES = [
     dict(name="als_weighted_mb", n_cells=160, n_genes=72, seed=24, T=6, fit_kwargs=dict(batch_size=48, sampling_method="weighted"),
          covariates=[("c1", ["x", "y", "z"], 0.0), ("c2", ["p", "q"], 0.0)],
          params=dict(n_components=5, n_covariate_components=[2, 3], lam=[1e3, 5e2], use_als=True, orth_W=0.05, alpha_W=0.3, l1_ratio_W=0.5)),
+    # non-default eps and seed, pure-L1 regulariser (l1_ratio_W = 1)
+    dict(name="nondefault", transform_iters=6, n_cells=130, n_genes=70, seed=25, T=25,
+         covariates=[("cond", ["a", "b", "c"], 0.0)],
+         params=dict(n_components=5, n_covariate_components=[3], lam=[50.0], eps=1e-4, random_state=7,
+                     orth_W=0.2, alpha_W=0.1, l1_ratio_W=1.0)),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,
