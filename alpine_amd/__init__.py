@@ -2,15 +2,11 @@
 
 Drop-in for ``ALPINE(**params).fit(adata, covariate_keys=...)`` / ``store_embeddings`` of
 ylaboratory/ALPINE; the loop runs in libalpine_hip.so (hand-written gfx950 kernels)."""
-import os as _os
-
-# Multi-process GPU work on this platform needs dmabuf IPC (RCCL's and torch's cross-process handles fail with
-# "hipIpcGetMemHandle: invalid argument" in the legacy mode).  The HIP runtime reads the variable when it starts, i.e. at the
-# first GPU call, so a default set at import time is in effect unless the caller has already touched the GPU or chosen a value.
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-from .anndata_compat import AnnData, MiniAnnData        # noqa: E402
-from .model import ALPINE                                # noqa: E402
+# (Importing this package changes nothing in the process environment.  Multi-process GPU work needs dmabuf IPC --
+# HSA_ENABLE_IPC_MODE_LEGACY=0, read when the HIP runtime starts; the sharded entry points -- fit(shard_cells=...), bench.py's
+# workers -- set that default themselves via alpine_amd.sharded.ensure_dmabuf_ipc.)
+from .anndata_compat import AnnData, MiniAnnData
+from .model import ALPINE
 
 __all__ = ["ALPINE", "AnnData", "MiniAnnData"]
 __version__ = "0.1.0"

@@ -30,7 +30,7 @@ EXPORTS = [
     "alpine_set_factors", "alpine_get_factors", "alpine_iter_begin", "alpine_iter_end", "alpine_reduce_block",
     "alpine_als_begin", "alpine_als_group_begin", "alpine_als_group_end", "alpine_reduce_block_hht", "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_get_kernel_time", "alpine_read_buffer",
-    "alpine_comm_get_unique_id", "alpine_comm_init_rank", "alpine_comm_destroy", "alpine_comm_all_reduce", "alpine_iter",
+    "alpine_comm_get_unique_id", "alpine_comm_version", "alpine_comm_init_rank", "alpine_comm_destroy", "alpine_comm_all_reduce", "alpine_iter",
 ]
 
 
@@ -54,6 +54,8 @@ class AlpineInfo(C.Structure):
         ("genes_padded", C.c_int64), ("cells_padded", C.c_int64),
         ("reduce_block_floats", C.c_int64), ("device_bytes", C.c_int64), ("x_sqnorm", C.c_double),
         ("x_multi_plane_fraction", C.c_double), ("x3_wide", C.c_int32), ("reserved", C.c_int32),
+        ("span_rows_a", C.c_int32), ("span_rows_b", C.c_int32),
+        ("spans_per_workgroup_a", C.c_int32), ("spans_per_workgroup_b", C.c_int32),
     ]
 
 
@@ -115,6 +117,7 @@ def load() -> C.CDLL:
     lib.alpine_read_buffer.argtypes = [p, i32, i64, i64, p]
     lib.alpine_comm_get_unique_id.argtypes = [p]
     lib.alpine_comm_init_rank.argtypes = [p, p, i32, i32]
+    lib.alpine_comm_version.argtypes = [C.POINTER(C.c_int)]
     lib.alpine_comm_destroy.argtypes = [p]
     lib.alpine_comm_all_reduce.argtypes = [p, i64, i64]
     lib.alpine_iter.argtypes = [p, i32]
@@ -348,6 +351,16 @@ def comm_unique_id() -> bytes:
     if rc != 0:
         raise AlpineNativeError(rc, lib.alpine_last_error(None).decode())
     return buf.raw
+
+
+def comm_version() -> int:
+    """ncclGetVersion of the librccl the library is linked against (an integer such as 22203)."""
+    lib = load()
+    v = C.c_int()
+    rc = lib.alpine_comm_version(C.byref(v))
+    if rc != 0:
+        raise AlpineNativeError(rc, lib.alpine_last_error(None).decode())
+    return int(v.value)
 
 
 def reduce_block_floats(n_genes: int, n_cells: int, n_components: int, cov_components: Sequence[int],

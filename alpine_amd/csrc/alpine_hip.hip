@@ -18,6 +18,8 @@
 
 using namespace alpine;
 
+static_assert(SG_MAX_CHAIN == ALPINE_MAX_ACCUMULATION_ROWS, "include/alpine_hip.h documents the accumulation cap");
+
 static thread_local std::string g_create_error;
 
 // The cells an iteration works on: the whole shard, or a gathered mini-batch (main.py:509-521).
@@ -40,6 +42,7 @@ struct alpine_ctx {
     CovMeta meta{};
     int nstat = 0, nB = 0, nYrows = 0;
     int device = 0, n_cu = 256;
+    size_t lds_max = 160 * 1024;      // LDS a workgroup may use (hipDeviceAttributeMaxSharedMemoryPerBlock)
     // stream
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -240,8 +243,12 @@ extern "C" int64_t alpine_reduce_block_floats(const alpine_config* cfg)
 }
 
 // Stream-K geometry of a sweep (see SweepGeom in kernels.hpp): a fixed grid of `slots` workgroups (as many as the
-// chip holds at once), each an equal span of L rows of the (tile,row) space.  forced > 0 asks for about `forced`
-// pieces per tile instead (tests use it to exercise spans that do / do not cross tiles).
+// chip holds at once), each an equal share of the (tile,row) space.  forced > 0 asks for about `forced` workgroups per
+// tile instead (tests use it to exercise shares that do / do not cross tiles).  A workgroup's share is cut into `sub`
+// equal spans of L <= SG_MAX_CHAIN rows: it restarts its float32 accumulators at every span boundary and writes a piece
+// per span and tile, so the length of an accumulator chain -- and with it the rounding error of a sweep, which has the
+// same sign every iteration because X does not change -- is bounded independently of the shard size (the spans' pieces
+// are summed in float64 by the consumers).  cfg3's shares are 15 4xx-15 6xx rows: sub = 1, nothing changes there.
 static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced, int bf = SG_BLOCK_F)
 {
     SweepGeom g{};
@@ -250,11 +257,14 @@ static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced, int bf =
     const int64_t total = (int64_t)g.nft * R;
     int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
     want = std::max<int64_t>(1, std::min<int64_t>(want, total / SG_ROW_ALIGN));
-    g.L = (int)round_up((total + want - 1) / want, SG_ROW_ALIGN);
+    const int64_t share = round_up((total + want - 1) / want, SG_ROW_ALIGN);         // rows per workgroup
+    g.sub = (int)((share + SG_MAX_CHAIN - 1) / SG_MAX_CHAIN);
+    g.L = (int)round_up((share + g.sub - 1) / g.sub, SG_ROW_ALIGN);
     g.nwg = (int)((total + g.L - 1) / g.L);
     g.maxp = (int)((g.L + R - 1) / R) + 1;
     return g;
 }
+static inline int sweep_grid(const SweepGeom& g) { return (g.nwg + g.sub - 1) / g.sub; }
 
 static int gram_rows_per_wave(int64_t R, int n_cu)
 {
@@ -294,6 +304,11 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, ALPINE_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
     c->n_cu = prop.multiProcessorCount;
+    {
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) == hipSuccess && (size_t)lds > c->lds_max) c->lds_max = (size_t)lds;   // gfx950: 160 KiB per CU
+        if (const char* e = std::getenv("ALPINE_HIP_LDS_LIMIT")) { const long v = std::atol(e); if (v > 0 && (size_t)v < c->lds_max) c->lds_max = (size_t)v; }   // tests: exercise the fall-backs
+    }
     c->unfused_mid = getenv_is("ALPINE_HIP_UNFUSED_MID", '1');
     c->no_tail = getenv_is("ALPINE_HIP_NO_TAIL", '1') || c->unfused_mid;
     c->fused_w = !getenv_is("ALPINE_HIP_FUSED_W", '0') && !c->unfused_mid;
@@ -341,12 +356,18 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     if (c->x3_ablate || !c->x3 || c->KT > 2) c->x3_narrow_pref = false;   // (the diagnostics build's ablated kernels are 1024-column only)
     c->batch_cap = cfg->batch_capacity;
     c->split_a_hint = cfg->split_a; c->split_b_hint = cfg->split_b;
-    // pieces: nwg * maxp tiles of bf x KP floats; mini-batch views have their own geometry, bounded by nft + 2 * nwg + maxp
-    // pieces.  Sized for every tile width this ctx may use.
+    // pieces: nwg * maxp tiles of bf x KP floats; mini-batch views have their own geometry (alpine_batch_begin), one per
+    // view size.  Sized for every tile width and every view size this ctx may use.
     auto piece_floats = [&](int bf, int64_t* capA, int64_t* capB) {
         const SweepGeom a = make_geom(Gp, Np, slots, cfg->split_a, bf), b = make_geom(Np, Gp, slots, cfg->split_b, bf);
         int64_t ta = (int64_t)a.nwg * a.maxp, tb = (int64_t)b.nwg * b.maxp;
-        if (c->batch_cap > 0) { ta = std::max<int64_t>(ta, (int64_t)a.nft + 2 * slots + 8); tb = std::max<int64_t>(tb, (int64_t)b.nft + 2 * slots + 8); }
+        if (c->batch_cap > 0) {
+            const int64_t Bp_max = round_up(std::min<int64_t>(c->batch_cap, (int64_t)1 << 30), 128);
+            for (int64_t Bp = 128; Bp <= Bp_max; Bp += 128) {
+                const SweepGeom va = make_geom(Gp, Bp, slots, 0, bf), vb = make_geom(Bp, Gp, slots, 0, bf);
+                ta = std::max<int64_t>(ta, (int64_t)va.nwg * va.maxp); tb = std::max<int64_t>(tb, (int64_t)vb.nwg * vb.maxp);
+            }
+        }
         *capA = std::max(*capA, ta * bf * KP); *capB = std::max(*capB, tb * bf * KP);
     };
     const int bf_default = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
@@ -473,7 +494,7 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     if (!c || !info) return fail(c, ALPINE_ERR_BAD_ARG, "NULL argument");
     info->abi_version = ALPINE_HIP_ABI_VERSION;
     info->k_total = c->K; info->k_padded = c->KP;
-    info->split_a = c->geomA.maxp; info->split_b = c->geomB.maxp; info->grid_a = c->geomA.nwg; info->grid_b = c->geomB.nwg;
+    info->split_a = c->geomA.maxp; info->split_b = c->geomB.maxp; info->grid_a = sweep_grid(c->geomA); info->grid_b = sweep_grid(c->geomB);
     info->genes_padded = c->Gp; info->cells_padded = c->Np;
     info->reduce_block_floats = c->red_floats;
     info->device_bytes = (int64_t)c->bytes;
@@ -481,6 +502,8 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     info->x_multi_plane_fraction = c->x_multi_plane_frac;
     info->x3_wide = c->x3 && c->x3_wide ? 1 : 0;
     info->reserved = 0;
+    info->span_rows_a = c->geomA.L; info->span_rows_b = c->geomB.L;
+    info->spans_per_workgroup_a = c->geomA.sub; info->spans_per_workgroup_b = c->geomB.sub;
     return 0;
 }
 
@@ -798,10 +821,10 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
 #define BF_ARGS S, (which == 0 ? c->x_plane_ng : c->x_plane_gn), panel, p_plane, master, pieces, g
 #define BF_LAUNCH(NPX, NPP) do { \
         if (g.bf == 8 * SG_WAVE_F) {          /* 8 waves: K <= 64 only (create_impl) */ \
-            if (c->KT == 1) hipLaunchKernelGGL((stream_gemm_bf16_kernel<1, NPX, NPP, 8>), dim3(g.nwg), dim3(512), 0, c->stream, BF_ARGS); \
-            else            hipLaunchKernelGGL((stream_gemm_bf16_kernel<2, NPX, NPP, 8>), dim3(g.nwg), dim3(512), 0, c->stream, BF_ARGS); \
+            if (c->KT == 1) hipLaunchKernelGGL((stream_gemm_bf16_kernel<1, NPX, NPP, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
+            else            hipLaunchKernelGGL((stream_gemm_bf16_kernel<2, NPX, NPP, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
         } else { \
-            DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP, 4>), dim3(g.nwg), dim3(256), 0, c->stream, BF_ARGS)); \
+            DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP, 4>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, BF_ARGS)); \
         } } while (0)
     if (!c->split) { BF_LAUNCH(1, 1); }
     else if (c->npx == 1) { BF_LAUNCH(1, 3); }
@@ -823,8 +846,8 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         if (c->x3_wide && !c->x3_ablate) {
             const bool pad_tile = c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
 #define X3W_LAUNCH(KT_, NH_) do { \
-                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
-                else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
+                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
+                else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
             switch (c->KT) {
                 case 1: if (c->x3_narrow) X3W_LAUNCH(1, 1); else X3W_LAUNCH(1, 2); break;
                 case 2: if (c->x3_narrow) X3W_LAUNCH(2, 1); else X3W_LAUNCH(2, 2); break;
@@ -837,26 +860,26 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         }
         switch (c->KT) {
             case 1:
-                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
             case 2:
 #ifdef ALPINE_DIAGNOSTICS
-                if (c->x3_ablate == 1) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
-                if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
-                if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
+                if (c->x3_ablate == 1) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
+                if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
+                if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
 #endif
-                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
                 break;
-            case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
-            default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(g.nwg), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
         }
         HIPCHK(c, hipGetLastError());
         return 0;
     }
 #define SG_LAUNCH(RING, PASSES) \
-    DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_kernel<KT_, RING, PASSES>), dim3(g.nwg), dim3(SG_THREADS), 0, c->stream, S, P, pieces, ldS, g, (unsigned long long*)nullptr))
+    DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_kernel<KT_, RING, PASSES>), dim3(sweep_grid(g)), dim3(SG_THREADS), 0, c->stream, S, P, pieces, ldS, g, (unsigned long long*)nullptr))
     switch (c->sg_variant) {
         case 1: SG_LAUNCH(8, 4); break;
         case 2: SG_LAUNCH(8, 2); break;
@@ -996,14 +1019,29 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
     } else {
         HTail tail{};
         const int hblocks = (int)((v.N + 127) / 128);
-        tail.ybuf_rows = (c->nYrows > 0 && c->nYrows <= HT_YROWS_MAX) ? c->nYrows : 0;      // Y of a block's cells in LDS
-        h_bytes_mfma += sizeof(float) * (size_t)tail.ybuf_rows * HS_CELLS;
+        // Optional LDS on top of the update's own (2 W^T W, B, the waves' tiles: ~134 KB at K > 96): the Y copy of the block's
+        // cells and the fused tail's statistics scratch.  Both are dropped when the total would exceed the CU's LDS -- Y is
+        // then read from global memory and the next phase 1 runs phase1_open_kernel instead of finding its inputs in the tail
+        // (same results, one more launch) -- e.g. K = 100 with a covariate of k = 10 and 30 levels plus a second covariate.
+        const size_t base = h_bytes_mfma;
+        int max_k = 1, max_ct = 1;
+        cov_maxima(c, &max_k, &max_ct);
+        auto total_bytes = [&](int ybuf_rows, bool tail_on) {
+            size_t b = base + sizeof(float) * (size_t)ybuf_rows * HS_CELLS;
+            if (tail_on) b += ybuf_rows ? hstats_tail_bytes(max_k, max_ct) : 2 * hstats_group_bytes(max_k, max_ct);
+            return b;
+        };
+        int ybuf_rows = (c->nYrows > 0 && c->nYrows <= HT_YROWS_MAX) ? c->nYrows : 0;      // Y of a block's cells in LDS
+        if (total_bytes(ybuf_rows, with_tail) > c->lds_max && ybuf_rows && total_bytes(0, with_tail) <= c->lds_max) ybuf_rows = 0;
+        if (total_bytes(ybuf_rows, with_tail) > c->lds_max) { with_tail = false; }
+        if (total_bytes(ybuf_rows, with_tail) > c->lds_max) ybuf_rows = 0;
+        if (total_bytes(ybuf_rows, with_tail) > c->lds_max)
+            return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the H update needs %zu bytes of LDS, the device has %zu", total_bytes(ybuf_rows, with_tail), c->lds_max);
+        tail.ybuf_rows = ybuf_rows;
+        h_bytes_mfma = total_bytes(ybuf_rows, with_tail);
         if (with_tail) {
-            int max_k, max_ct;
-            cov_maxima(c, &max_k, &max_ct);
             tail.gram_part = c->gramPartH; tail.stat_part = c->statPartH;
             tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
-            h_bytes_mfma += tail.ybuf_rows ? hstats_tail_bytes(max_k, max_ct) : 2 * hstats_group_bytes(max_k, max_ct);
         }
         if (c->loss_type == ALPINE_LOSS_KL) {
             DISPATCH_KT(c->KT, hipLaunchKernelGGL((h_update_mfma_kernel<KT_, 0>), dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
@@ -1205,6 +1243,13 @@ extern "C" int alpine_comm_get_unique_id(void* id_out)
     ncclUniqueId id;
     NCCLCHK(nullptr, ncclGetUniqueId(&id));
     std::memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int alpine_comm_version(int* version_out)
+{
+    if (!version_out) return fail(nullptr, ALPINE_ERR_BAD_ARG, "version_out is NULL");
+    NCCLCHK(nullptr, ncclGetVersion(version_out));
     return 0;
 }
 

@@ -64,6 +64,7 @@ constexpr int SG_WAVES = 4;
 constexpr int SG_WAVE_F = 128;
 constexpr int SG_BLOCK_F = SG_WAVES * SG_WAVE_F;
 constexpr int SG_ROW_ALIGN = 64;     // split boundaries are multiples of this (>= rows per panel stage of every variant)
+constexpr int SG_MAX_CHAIN = 16384;  // longest run of contraction rows one float32 accumulator may cover (see SweepGeom::sub)
 
 // One panel stage = SG_RING k-steps.  Software pipeline per k-step p (all indices static):
 //   ds_read  A operands of step p+1          (LDS latency hidden behind the 8..16 MFMAs of step p)
@@ -108,10 +109,43 @@ struct SweepGeom {
     int bf;       // f columns per workgroup tile: 128 per wave (512 with 4 waves; 1024 for the 8-wave bf16 sweeps)
     int nft;      // bf-wide f tiles
     int L;        // rows of (tile,row) space per workgroup, multiple of SG_ROW_ALIGN
-    int nwg;      // workgroups
-    int maxp;     // pieces per workgroup
+    int nwg;      // spans (= piece owners); the launch grid is ceil(nwg / sub) workgroups
+    int maxp;     // pieces per span
+    int sub;      // consecutive spans per workgroup: a workgroup restarts its accumulators at every span boundary, so no
+                  // float32 accumulator chain covers more than L <= SG_MAX_CHAIN contraction rows whatever the shard size
     int panel_fixed;  // timing-only ablation of the bf16 sweeps: every panel stage re-reads stage 0 (cache-resident) -> wrong results
 };
+
+// A workgroup's walk over its `sub` consecutive spans, cut at tile boundaries into segments (tile ft, rows [r_begin, r_end)
+// of that tile); every segment owns one piece: slot = span * maxp + (ft - first tile of the span).  All wave-uniform.
+struct SgWalk {
+    int64_t pos, pos_end, span_end;
+    int span, first_tile;
+};
+__device__ __forceinline__ void sg_walk_init(SgWalk& s, const SweepGeom& g, int wg)
+{
+    const int64_t total = (int64_t)g.nft * g.R;
+    s.span = wg * g.sub;
+    s.pos = (int64_t)s.span * g.L;
+    s.pos_end = min(total, s.pos + (int64_t)g.sub * g.L);
+    s.span_end = min(s.pos_end, s.pos + g.L);
+    s.first_tile = (int)(s.pos / g.R);
+}
+__device__ __forceinline__ bool sg_walk_next(SgWalk& s, const SweepGeom& g, int& ft, int& r_begin, int& r_end, int64_t& slot)
+{
+    if (s.pos >= s.pos_end) return false;
+    if (s.pos == s.span_end) {                   // next span of this workgroup: fresh accumulators, fresh pieces
+        ++s.span;
+        s.span_end = min(s.pos_end, s.span_end + g.L);
+        s.first_tile = (int)(s.pos / g.R);
+    }
+    ft = (int)(s.pos / g.R);
+    r_begin = (int)(s.pos - (int64_t)ft * g.R);
+    r_end = (int)min((int64_t)g.R, r_begin + (s.span_end - s.pos));
+    s.pos += r_end - r_begin;
+    slot = (int64_t)s.span * g.maxp + (ft - s.first_tile);
+    return true;
+}
 
 // pieces that contribute to tile ft: workgroups w_lo..w_hi; piece index of w for this tile
 __device__ __forceinline__ void sg_tile_pieces(const SweepGeom& g, int ft, int& w_lo, int& w_hi)
@@ -181,21 +215,16 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar branches
     const int c = lane & 31, h = lane >> 5;
-    const int w = blockIdx.x;
-    const int64_t total = (int64_t)g.nft * g.R;
-    int64_t pos = (int64_t)w * g.L;
-    const int64_t pos_end = min(total, pos + g.L);
-    const int first_tile = (int)(pos / g.R);
+    SgWalk walk;
+    sg_walk_init(walk, g, blockIdx.x);
     const int lds_lane = h * KP + c;
 
     f32x4 preg[PV];
     f32x4 x[SG_RING];
 
-    while (pos < pos_end) {
-        const int ft = (int)(pos / g.R);
-        const int r_begin = (int)(pos - (int64_t)ft * g.R);
-        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
-        pos += r_end - r_begin;
+    int ft, r_begin, r_end;
+    int64_t slot;
+    while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
         const int nst = (r_end - r_begin) / SG_CH;                 // >= 1 (everything is a multiple of SG_ROW_ALIGN)
         const int f0 = (ft * SG_WAVES + wave) * SG_WAVE_F;
         const bool active = f0 < g.F;
@@ -283,7 +312,7 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
         }
 
         // D row (k within tile m) = 8q + 4h + e, D column = lane & 31 = c -> f_local = 128*wave + 4c + j
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * SG_BLOCK_F + wave * SG_WAVE_F) * KP;
+        float* out = pieces + (slot * SG_BLOCK_F + wave * SG_WAVE_F) * KP;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x16* d[KT];

@@ -252,22 +252,17 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int w = blockIdx.x;
-    const int64_t total = (int64_t)g.nft * g.R;
-    int64_t pos = (int64_t)w * g.L;
-    const int64_t pos_end = min(total, pos + g.L);
-    const int first_tile = (int)(pos / g.R);
+    SgWalk walk;
+    sg_walk_init(walk, g, blockIdx.x);
     const int64_t f_stride8 = (int64_t)g.F * 8;                     // bf16 elements between consecutive 8-row blocks of S
 
     u32x4 preg[PV];                                                 // NPP == 1: staged bf16 granules
     float pf[NPP == 1 ? 1 : ((BF_ROWS / 8) * KP + NT - 1) / NT][8];   // NPP == 3: staged float32 panel values
     u32x4 x[BF_RING][NPX][4];
 
-    while (pos < pos_end) {
-        const int ft = (int)(pos / g.R);
-        const int r_begin = (int)(pos - (int64_t)ft * g.R);
-        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
-        pos += r_end - r_begin;
+    int ft, r_begin, r_end;
+    int64_t slot;
+    while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
         const int nst = (r_end - r_begin) / BF_ROWS;
         const int f0 = (ft * NW + wave) * SG_WAVE_F;
         const bool active = f0 < g.F;
@@ -380,7 +375,7 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
         bf_stage<KT, NPX, NPP, BF_RING, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = 128*wave + 32*j + c
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * (NW * SG_WAVE_F) + wave * SG_WAVE_F) * KP;
+        float* out = pieces + (slot * (NW * SG_WAVE_F) + wave * SG_WAVE_F) * KP;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x16* d[KT];

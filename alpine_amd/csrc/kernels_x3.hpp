@@ -162,20 +162,15 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int w = blockIdx.x;
-    const int64_t total = (int64_t)g.nft * g.R;
-    int64_t pos = (int64_t)w * g.L;
-    const int64_t pos_end = min(total, pos + g.L);
-    const int first_tile = (int)(pos / g.R);
+    SgWalk walk;
+    sg_walk_init(walk, g, blockIdx.x);
 
     float pf[PVS][8];
     f32x4 x[X3_RING][NH][8];
 
-    while (pos < pos_end) {
-        const int ft = (int)(pos / g.R);
-        const int r_begin = (int)(pos - (int64_t)ft * g.R);
-        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
-        pos += r_end - r_begin;
+    int ft, r_begin, r_end;
+    int64_t slot;
+    while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
         const int nst = (r_end - r_begin) / X3_ROWS;
         const int f0 = (ft * 4 + wave) * WAVE_F;
         const bool active = f0 < g.F;
@@ -274,7 +269,7 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;
+        float* out = pieces + (slot * BLOCK_F + wave * WAVE_F) * KP;
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
             if ((hf == 1 && f1 == f0) || g.panel_fixed == 2) break;    // second half outside F: nothing to write (panel_fixed == 2: timing-only ablation of the flush)
@@ -356,20 +351,15 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, kg = lane >> 4;
-    const int w = blockIdx.x;
-    const int64_t total = (int64_t)g.nft * g.R;
-    int64_t pos = (int64_t)w * g.L;
-    const int64_t pos_end = min(total, pos + g.L);
-    const int first_tile = (int)(pos / g.R);
+    SgWalk walk;
+    sg_walk_init(walk, g, blockIdx.x);
 
     float pf[PVS][8];
     f32x4 x[NCG][8];
 
-    while (pos < pos_end) {
-        const int ft = (int)(pos / g.R);
-        const int r_begin = (int)(pos - (int64_t)ft * g.R);
-        const int r_end = (int)min((int64_t)g.R, r_begin + (pos_end - pos));
-        pos += r_end - r_begin;
+    int ft, r_begin, r_end;
+    int64_t slot;
+    while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
         const int nst = (r_end - r_begin) / ROWS;
         const int f0 = (ft * 4 + wave) * WAVE_F;
         const bool active = f0 < g.F;
@@ -511,7 +501,7 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
         stage(&lds[t & 1][lds_lane], 0, true);
 
         // D: component = 16 m + 4 kg + e, column = c16 -> f_local = WAVE_F * wave + 64 cg + 4 c16 + t
-        float* out = pieces + (((int64_t)w * g.maxp + (ft - first_tile)) * BLOCK_F + wave * WAVE_F) * KP;
+        float* out = pieces + (slot * BLOCK_F + wave * WAVE_F) * KP;
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
             if (cg >= 2 && !half2) break;                  // second half outside F: nothing to write

@@ -22,7 +22,7 @@ from . import _native
 from .anndata_compat import is_anndata
 from .encoder import FeatureEncoders
 from .sharded import (NativeComm, ShardedLoop, TorchDistComm, all_ranks_ok, attach_native_comm, check_shardable,
-                      native_comm_possible, shard_bounds)
+                      ensure_dmabuf_ipc, native_comm_possible, shard_bounds)
 
 Float32Array = np.ndarray
 
@@ -154,7 +154,7 @@ class ALPINE:
         shard_cells: Union[bool, str] = False,
         x_dtype: str = "x3",
         shard_comm: str = "auto",
-        keep_resident: bool = True,
+        keep_resident: bool = False,
     ):
         self.n_components = n_components
         self.n_covariate_components = n_covariate_components
@@ -184,9 +184,12 @@ class ALPINE:
         if shard_comm not in ("auto", "native", "torch"):
             raise ValueError("shard_comm must be 'auto', 'native' or 'torch'")
         self.shard_comm = shard_comm
-        # extension: after a single-device fit the engine (with both copies of X in HBM) stays alive, so that a following
-        # compute_loss(adata) / transform(adata) ON THE SAME adata.X does not upload X again (at 20k x 200k one upload costs
-        # as much as 50-100 iterations).  release() frees it; False frees it at the end of fit() like the reference does.
+        # extension (off by default, as in the reference, which frees everything at the end of fit): keep_resident=True leaves
+        # the engine -- with both float32 copies of X in HBM, ~30 GiB at 20k x 200k -- alive after a single-device fit, so
+        # that a following compute_loss(adata) / transform(adata) ON THE SAME adata.X does not upload X again (one upload
+        # costs as much as 50-100 iterations at that size).  The resident copy is used only while adata.X is the same
+        # object with the same buffer, shape, strides, dtype AND whole-array checksum; any mismatch releases it.
+        # release() frees it explicitly.
         if not isinstance(keep_resident, bool):
             raise TypeError("keep_resident must be a boolean.")
         self.keep_resident = keep_resident
@@ -336,16 +339,27 @@ class ALPINE:
     # ------------------------------------------------------------------ resident engine
     @staticmethod
     def _x_fingerprint(X: np.ndarray):
-        """Cheap identity of an input matrix: buffer address, shape, strides, dtype and a hash of 64 evenly spaced rows.
-        (An in-place edit of X that misses all sampled rows is not detected -- call release() after mutating X.)"""
-        import hashlib
-        rows = np.unique(np.linspace(0, max(0, X.shape[0] - 1), num=min(64, max(1, X.shape[0]))).astype(np.int64))
-        h = hashlib.blake2b(np.ascontiguousarray(X[rows]).tobytes(), digest_size=16).hexdigest()
-        return (X.ctypes.data, X.shape, X.strides, X.dtype.str, h)
+        """Identity of an input matrix: buffer address, shape, strides, dtype and a checksum over EVERY element (float64 sums
+        of the raw 32-bit words, one per 64 MB block, threaded like all_nonnegative: ~0.1 s at 20k x 200k), so an in-place
+        edit anywhere in X is seen -- the reference re-reads adata.X on every call."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        A = X if X.flags.c_contiguous else (X.T if X.T.flags.c_contiguous else np.ascontiguousarray(X))
+        if A.dtype.itemsize not in (4, 8):
+            A = np.ascontiguousarray(A, dtype=np.float32)
+        flat = A.reshape(-1).view(np.uint32 if A.dtype.itemsize == 4 else np.uint64)
+        step = 1 << 24
+        blocks = [(a, min(flat.shape[0], a + step)) for a in range(0, flat.shape[0], step)]
+        with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1, len(blocks)))) as pool:
+            sums = tuple(pool.map(lambda ab: float(flat[ab[0]:ab[1]].sum(dtype=np.float64)), blocks))
+        return (X.ctypes.data, X.shape, X.strides, X.dtype.str, sums)
 
     def _resident_engine_for(self, X: np.ndarray):
         r = self._resident
-        if r is None or r["X"] is not X or r["fingerprint"] != self._x_fingerprint(X):
+        if r is None:
+            return None
+        if r["X"] is not X or r["fingerprint"] != self._x_fingerprint(X):
+            self.release()                            # another matrix, or the fitted one was edited: the HBM copy is stale
             return None
         return r["eng"]
 
@@ -368,6 +382,8 @@ class ALPINE:
         dist, rank, world = self._dist_world()
         sharded = dist is not None
         local_input = sharded and self.shard_cells == "local"
+        if sharded:
+            ensure_dmabuf_ipc()                        # before this process's first GPU call, if it has not made one yet
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: alpine_amd needs an MI355X (there is no CPU fallback)")
         if dev_index < 0:
@@ -458,13 +474,21 @@ class ALPINE:
             comm = None
             if sharded:
                 mode = self.shard_comm
+                self.shard_comm_note = None
                 if mode == "auto":
                     mode = "native" if native_comm_possible(dist, dev_index) else "torch"
-                if mode == "native":
+                    if mode == "native":
+                        # the library's communicator is the default carrier, but "auto" must not turn a communicator
+                        # set-up failure into a failed fit: attach_native_comm raises on EVERY rank together, so all
+                        # ranks take the torch.distributed carrier together
+                        try:
+                            attach_native_comm(eng, dist)
+                        except Exception as e:          # noqa: BLE001
+                            mode = "torch"
+                            self.shard_comm_note = f"native communicator failed ({type(e).__name__}: {e}); fell back to torch.distributed"
+                elif mode == "native":
                     attach_native_comm(eng, dist)
-                    comm = NativeComm(eng)
-                else:
-                    comm = TorchDistComm(block)
+                comm = NativeComm(eng) if mode == "native" else TorchDistComm(block)
                 self.shard_comm_used = mode
             for i, y in enumerate(Y):
                 eng.upload_Y(i, np.ascontiguousarray(y[row0:row0 + n_loc].T))

@@ -65,16 +65,33 @@ def native_comm_possible(dist, device_index: int) -> bool:
     return len(set(devs)) == len(devs)
 
 
+def ensure_dmabuf_ipc() -> None:
+    """Multi-process GPU work on this platform needs dmabuf IPC (RCCL's and torch's cross-process handles fail with
+    "hipIpcGetMemHandle: invalid argument" in the legacy mode).  The HIP runtime reads the variable when it starts, so the
+    sharded entry points set the default before their first GPU call; a value chosen by the caller is left alone."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def attach_native_comm(engine, dist, group=None) -> None:
     """Give ``engine`` an RCCL communicator over the ranks of the torch.distributed group: rank 0 draws the unique id
-    through the library, torch broadcasts its 128 bytes (control plane only), every rank joins.  Collective."""
+    through the library, torch broadcasts its 128 bytes (control plane only), every rank joins.  Collective: a failure on
+    any rank (rank 0 drawing the id, any rank joining) raises on EVERY rank, so nobody is left blocked in a later collective."""
     from . import _native
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [_native.comm_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box = [("id", _native.comm_unique_id())]
+        except Exception as e:      # noqa: BLE001 -- librccl missing, ncclGetUniqueId error: tell the peers instead of leaving them in the broadcast
+            box = [("error", f"{type(e).__name__}: {e}")]
     dist.broadcast_object_list(box, src=0, group=group)
+    kind, payload = box[0]
+    if kind != "id":
+        raise RuntimeError(f"rank 0 could not create the communicator id: {payload}")
     err = None
     try:
-        engine.comm_init(box[0], world, rank)
+        engine.comm_init(payload, world, rank)
     except Exception as e:          # noqa: BLE001 -- agree with the peers before raising
         err = e
     all_ranks_ok(dist, err is None, "alpine_comm_init_rank", err)

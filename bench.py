@@ -27,8 +27,9 @@ Rank 0 prints ONE JSON line (see the repo's driver contract) with two extra obje
   roofline     -- the dominant kernel (the streaming sweep, 2 launches/iteration): algorithmic bytes (or, for
                   --dtype f32, flops) per launch / average launch time measured live with hipEvents on the
                   kernel's stream, against the 8 TB/s HBM peak (f32: the 157.3 TF float32 MFMA peak)
-  cpu_baseline -- the oracle's faithful torch-CPU restatement of the reference loop timed on this
-                  host's cores on a bounded sample (fewer cells), extrapolated linearly in cells
+  cpu_baseline -- the oracle's faithful torch-CPU restatement of the reference loop timed on this host's cores: the
+                  whole workload directly when the host has > 250 GiB free (1 warm-up + 2 timed iterations, under a
+                  wall budget), else a 50 000-cell sample extrapolated linearly in cells; the branch taken is recorded
 """
 from __future__ import annotations
 
@@ -45,6 +46,7 @@ sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBPS = 8000.0
+HBM_READ_CEILING_GBPS = 7100.0      # compute-free streaming read of the sweeps' tiles measured on MI355X (tools/xcd_balance.hip: 6.96-7.1 TB/s)
 FULLSIG_SCALE = 0.3712345          # multiplies the synthetic counts for the full-significand legs (every float32 then needs all three bf16 planes)
 
 WORKLOADS = {
@@ -68,7 +70,10 @@ def parse_args():
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra (non-headline) split / bf16 measurements at N=1")
     ap.add_argument("--no-loss", action="store_true", help="updates only (secondary number)")
     ap.add_argument("--cpu-sample-cells", type=int, default=0,
-                    help="cells of the CPU-baseline sample; 0 = 50000 (BASELINE config 2's size, ~25 GB RSS) when the host has the RAM, else 12000")
+                    help="cells of the CPU-baseline sample; 0 = the whole workload timed directly when MemAvailable > 250 GiB "
+                         "(~100 GB RSS at 20k x 200k), else 50000 (BASELINE config 2's size, ~25 GB RSS) or 12000")
+    ap.add_argument("--cpu-warmup-budget", type=float, default=45.0,
+                    help="seconds the warm-up iteration of the direct CPU leg may take before it falls back to the 50000-cell sample")
     ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                     help="N > 1: carrier of the all-reduce -- native = RCCL inside libalpine_hip (default), torch = torch.distributed")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 self-launch: watchdog over the workers, seconds")
@@ -91,14 +96,19 @@ def labels_onehot(n_cells: int, seed: int) -> np.ndarray:
     return Y
 
 
-def cpu_baseline(wl: dict, sample_cells: int, full_cells: int) -> dict:
-    """Oracle (faithful restatement of main.py:500-667 incl. randperm gather and per-iteration loss)
-    on torch-CPU, all host cores, on `sample_cells` cells of the same workload."""
+def cpu_baseline(wl: dict, sample_cells: int, full_cells: int, dev=None, warmup_budget_s: float = 45.0) -> dict:
+    """Oracle (faithful restatement of main.py:500-667 incl. randperm gather and per-iteration loss) on torch-CPU, all host
+    cores, on the same synthetic matrix the GPU legs ran on (generated on the device, copied to the host).
+
+    SURVEY.md 8d: time the metric's workload DIRECTLY when the host has the RAM (the reference needs ~6.2 x the bytes of X as
+    RSS, ~100 GB at 20k x 200k): `sample_cells` <= 0 and MemAvailable > 250 GiB -> all `full_cells` cells, 1 warm-up + 2 timed
+    iterations, guarded by a wall budget (warm-up iteration > `warmup_budget_s` -> fall back to the 50 000-cell sample,
+    extrapolated linearly in cells, as does a host with less memory)."""
     import resource
     import torch
-    from alpine_amd.datasets import synth_counts_host
     from oracle import alpine_oracle as orc
     G, ku, kcov = wl["genes"], wl["ku"], wl["kcov"]
+    t_leg = time.perf_counter()
     mem_avail_gb = None
     try:
         with open("/proc/meminfo") as f:
@@ -107,36 +117,65 @@ def cpu_baseline(wl: dict, sample_cells: int, full_cells: int) -> dict:
                     mem_avail_gb = int(line.split()[1]) / 2**20
     except OSError:
         pass
-    if sample_cells <= 0:
-        # the reference needs ~6.2 x the bytes of X as RSS (24 GB at 20k x 50k); take BASELINE config 2's
-        # size when the host has clearly more than that free, else the small sample
+    mem_txt = f"MemAvailable {mem_avail_gb:.0f} GiB" if mem_avail_gb is not None else "MemAvailable unknown"
+    if sample_cells > 0:
+        plan = [min(sample_cells, full_cells)]
+        branch = f"--cpu-sample-cells {sample_cells}"
+    elif mem_avail_gb is not None and mem_avail_gb > 250.0:
+        plan = [full_cells] + ([50000] if full_cells > 50000 else [])        # direct; the sample is the budget fall-back
+        branch = f"auto: {mem_txt} > 250 GiB -> all {full_cells} cells timed directly"
+    else:
+        # ~6.5 x the bytes of X as RSS (24 GB at 20k x 50k): BASELINE config 2's size when the host clearly has that, else small
         need_gb = 6.5 * 4.0 * G * 50000 / 2**30 + 8.0
         big = mem_avail_gb is not None and mem_avail_gb > 2.0 * need_gb
-        sample_cells = 50000 if big else 12000
-        branch = (f"auto: MemAvailable {mem_avail_gb:.0f} GiB {'>' if big else '<='} 2 x {need_gb:.0f} GiB -> {sample_cells} cells"
-                  if mem_avail_gb is not None else f"auto: MemAvailable unknown -> {sample_cells} cells")
+        plan = [min(full_cells, 50000 if big else 12000)]
+        branch = f"auto: {mem_txt} {'>' if big else '<='} 2 x {need_gb:.0f} GiB (and <= 250 GiB) -> {plan[0]} cells"
+
+    # genes x cells, the oracle's layout, straight from the device generator (a numpy Poisson draw of 4e9 elements would take
+    # longer than the timed iterations); without a device (tests of this function alone) the host generator
+    n_max = plan[0]
+    if dev is not None:
+        from alpine_amd.datasets import synth_counts_device_chunks
+        X_gn = np.empty((G, n_max), dtype=np.float32)
+        for off, chunk in synth_counts_device_chunks(n_max, G, rank=ku, seed=0, device=dev, chunk_cells=8192):
+            X_gn[:, off:off + chunk.shape[0]] = chunk.t().contiguous().cpu().numpy()
+            del chunk
+        torch.cuda.empty_cache()
     else:
-        branch = f"--cpu-sample-cells {sample_cells}"
-    sample_cells = min(sample_cells, full_cells)
-    X = synth_counts_host(sample_cells, G, rank=ku, seed=0)
-    Ys = [labels_onehot(sample_cells, seed=1 + i).T for i in range(len(kcov))]       # N x C
+        from alpine_amd.datasets import synth_counts_host
+        X_gn = np.ascontiguousarray(synth_counts_host(n_max, G, rank=ku, seed=0).T)
+    t_gen = time.perf_counter() - t_leg
     p = orc.OracleParams(n_components=ku, n_covariate_components=list(kcov), lam=[1e3] * len(kcov),
                          orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"])
-    t_leg = time.perf_counter()
-    s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
-    orc.fit_faithful(p, s, 1)                       # warm-up
-    n_it = 3
-    t0 = time.perf_counter()
-    orc.fit_faithful(p, s, n_it)
-    dt = time.perf_counter() - t0
+
+    fallback = None
+    for attempt, n_s in enumerate(plan):
+        Xs = X_gn if n_s == X_gn.shape[1] else np.ascontiguousarray(X_gn[:, :n_s])
+        Ys = [labels_onehot(n_s, seed=1 + i).T for i in range(len(kcov))]       # N x C
+        s = orc.init_factors(p, Xs, Ys)
+        t0 = time.perf_counter()
+        orc.fit_faithful(p, s, 1)                       # warm-up
+        t_warm = time.perf_counter() - t0
+        if attempt + 1 < len(plan) and t_warm > warmup_budget_s:
+            fallback = (f"the warm-up iteration at {n_s} cells took {t_warm:.1f} s > the {warmup_budget_s:.0f} s budget: "
+                        f"fell back to {plan[attempt + 1]} cells, scaled linearly")
+            del s
+            continue
+        n_it = 2 if n_s == full_cells and n_s > 50000 else 3
+        t0 = time.perf_counter()
+        orc.fit_faithful(p, s, n_it)
+        dt = time.perf_counter() - t0
+        break
+    del s
     it_s_sample = n_it / dt
     # the same mathematics in the re-associated minimal-op form (no G x N temporaries, trace-form loss) on the same cores:
     # separates the algorithmic part of the speed-up from the hardware part
-    s2 = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
+    s2 = orc.init_factors(p, Xs, Ys)
     orc.fit_fused(p, s2, 1, with_loss=True)
     t0 = time.perf_counter()
     orc.fit_fused(p, s2, n_it, with_loss=True)
     it_s_fused = n_it / (time.perf_counter() - t0)
+    del s2
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -146,56 +185,76 @@ def cpu_baseline(wl: dict, sample_cells: int, full_cells: int) -> dict:
                     break
     except OSError:
         pass
+    direct = n_s == full_cells
+    how = ("timed directly at the metric's size, no extrapolation" if direct else
+           f"measured {it_s_sample:.4f} it/s on the sample, scaled linearly in cells to {full_cells} (conservative: the reference "
+           f"scales super-linearly, BASELINE.md section 2)")
     return {
-        "value": it_s_sample * sample_cells / full_cells,
+        "value": it_s_sample * n_s / full_cells,
         "unit": "iterations/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": (f"oracle.fit_faithful (torch-CPU fp32 restatement of alpine/main.py:500-667 incl. randperm gather and "
-                   f"per-iteration loss), {G} genes x {sample_cells} cells of the same synthetic workload, {n_it} timed "
-                   f"iterations after 1 warm-up = {dt:.1f} s; measured {it_s_sample:.4f} it/s on the sample, scaled linearly "
-                   f"in cells to {full_cells} (conservative: the reference scales super-linearly, BASELINE.md section 2)"),
-        "measured_sample_it_per_s": it_s_sample, "sample_cells": sample_cells, "sample_branch": branch,
+                   f"per-iteration loss), {G} genes x {n_s} cells of the same synthetic matrix, {n_it} timed "
+                   f"iterations after 1 warm-up ({t_warm:.1f} s) = {dt:.1f} s; {how}"),
+        "measured_sample_it_per_s": it_s_sample, "sample_cells": n_s, "extrapolated": not direct, "sample_branch": branch,
+        "budget_fallback": fallback, "warmup_iteration_s": t_warm, "timed_iterations": n_it, "timed_s": dt, "matrix_to_host_s": t_gen,
         "peak_rss_GiB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20, 1), "mem_available_GiB_before": mem_avail_gb,
         "leg_seconds": time.perf_counter() - t_leg,
-        "fused_port_value": it_s_fused * sample_cells / full_cells,      # oracle.fit_fused, same sample and scaling
+        "fused_port_value": it_s_fused * n_s / full_cells,      # oracle.fit_fused, same sample and scaling
         "fused_port_measured_sample_it_per_s": it_s_fused,
         "host_cpu": cpu_model, "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
     }
 
 
-def pmc_traffic(workload: str, world: int, kp: int, dtype: str = "f32"):
+def pmc_traffic(workload: str, world: int, kp: int, dtype: str = "f32", fullsig: bool = False, kernel_name: str = ""):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (collected in separate
-    runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md); None when no matching profile exists."""
+    runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md); None when no matching profile exists.
+    `fullsig`: the leg ran on full-significand data -> the `_fullsig` profile of that mode (another kernel, other traffic);
+    the profile must be of the kernel that ran (`kernel_name`) and of the same k tiling."""
     import glob
+    import re
     if world != 1:
         return None
     best = None
-    import re
-    tag = {"f32": "", "bf16": "_bf16", "split": "_split", "x3": "_x3"}[dtype]
+    tag = {"f32": "", "bf16": "_bf16", "split": "_split", "x3": "_x3"}[dtype] + ("_fullsig" if fullsig else "")
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", f"{workload}{tag}_stream_gemm_pmc_summary.json"))):
         try:
             d = json.load(open(f))
             m = re.search(r"<(\d+)", d.get("kernel", ""))
-            if m and int(m.group(1)) == kp // 32:
+            same_kernel = not kernel_name or d.get("kernel", "").split("<")[0].strip() == kernel_name
+            if m and int(m.group(1)) == kp // 32 and same_kernel:
                 best = {"bytes_per_launch": d["traffic_bytes_per_launch"], "over_algorithmic": d["traffic_over_algorithmic"],
-                        "source": os.path.relpath(f, REPO)}
+                        "kernel": d.get("kernel"), "source": os.path.relpath(f, REPO)}
         except (OSError, ValueError, KeyError):
             pass
     return best
+
+
+def visible_gpu_count() -> int:
+    """GPUs this process tree may use, counted WITHOUT starting a GPU runtime in the caller (the launcher parent stays
+    GPU-free for its whole life; its workers are fresh processes): a short-lived child asks torch, which honours the
+    *_VISIBLE_DEVICES variables and the container's device permissions (sysfs would list the host's GPUs)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                           timeout=600)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        return 0
 
 
 def launch_workers(args) -> int:
     """`python bench.py --gpus N` outside a launcher: start N fresh worker processes (one per GPU) BEFORE this process
     makes any GPU call, relay rank 0's JSON line, fail loudly if a worker fails or the watchdog expires.  No exec of
     this process, no kill-by-pattern: only the PIDs started here are ever signalled."""
+    import collections
     import socket
     import subprocess
     import threading
-    import torch
     n = args.gpus
     rehearsal = os.environ.get("ALPINE_BENCH_REHEARSAL_ONE_GPU") == "1"
-    have = torch.cuda.device_count()            # counting devices does not initialise the GPU runtime
+    have = visible_gpu_count()                  # asked in a short-lived child: this parent never loads a GPU runtime
     if have < n and not rehearsal:
         print(f"bench.py --gpus {n}: only {have} GPU(s) visible (ALPINE_BENCH_REHEARSAL_ONE_GPU=1 rehearses N ranks on one "
               f"GPU over gloo)", file=sys.stderr)
@@ -207,6 +266,7 @@ def launch_workers(args) -> int:
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     procs, lines = [], []
+    tails = [collections.deque(maxlen=60) for _ in range(n)]       # last stderr lines of every rank, replayed on failure
 
     def pump(stream, keep):
         for line in stream:
@@ -216,14 +276,22 @@ def launch_workers(args) -> int:
                 sys.stderr.write(line)
         stream.close()
 
+    def pump_err(stream, r):
+        for line in stream:
+            tails[r].append(line)
+            sys.stderr.write(f"[rank {r}] {line}")
+        stream.close()
+
     threads = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True)
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True)
         procs.append(p)
-        t = threading.Thread(target=pump, args=(p.stdout, r == 0), daemon=True)
-        t.start()
-        threads.append(t)
+        for t in (threading.Thread(target=pump, args=(p.stdout, r == 0), daemon=True),
+                  threading.Thread(target=pump_err, args=(p.stderr, r), daemon=True)):
+            t.start()
+            threads.append(t)
     deadline = time.monotonic() + args.launch_timeout
     rc = 0
     while True:
@@ -252,6 +320,11 @@ def launch_workers(args) -> int:
                 p.kill()
     for t in threads:
         t.join(timeout=5)
+    if rc:
+        # one block per rank, so that the first failure is readable even when the ranks' output interleaved above
+        for r, p in enumerate(procs):
+            print(f"---- bench.py: rank {r} exit code {p.poll()}; last {len(tails[r])} stderr lines ----", file=sys.stderr)
+            sys.stderr.write("".join(tails[r]))
     if rc == 0 and len(lines) != 1:
         print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
         rc = 1
@@ -383,6 +456,29 @@ def main():
                     comm_state["carrier"] = f"torch.distributed.all_reduce ({dist.get_backend()}) on the ctx stream"
             loop = ShardedLoop(eng, comm) if world > 1 else None
 
+            def probe_allreduce():
+                """Before the timed loop (N > 1): one tiny all-reduce (pays the carrier's lazy connection set-up) and the
+                reduce-block-sized one on its own, host-timed with a device sync on both sides -- so that a slow first
+                iteration or a slow collective is visible in the JSON line instead of being folded into ms_per_step.
+                The block holds zeros here (phase 1 rewrites all of it every iteration)."""
+                def timed(n_floats, reps=1):
+                    eng.synchronize()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t = time.perf_counter()
+                    for _ in range(reps):
+                        comm.all_reduce_slice(0, n_floats)
+                    eng.synchronize()
+                    torch.cuda.synchronize()
+                    return 1e3 * (time.perf_counter() - t) / reps
+                nfl_ = int(info.reduce_block_floats)
+                first = timed(min(1024, nfl_))
+                first_full = timed(nfl_)
+                standalone = timed(nfl_, reps=10)
+                return {"first_call_ms": first, "first_full_block_ms": first_full, "standalone_ms": standalone}
+
+            ar_probe = probe_allreduce() if world > 1 else None
+
             def run(n):
                 if loop is not None:
                     loop.run(n, with_loss=with_loss)
@@ -447,7 +543,7 @@ def main():
             del block
             torch.cuda.empty_cache()
         return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen, dt_noloss=dt_noloss,
-                    ar_ms=ar_ms, x_scale=x_scale, event_stride=stride)
+                    ar_ms=ar_ms, x_scale=x_scale, event_stride=stride, ar_probe=ar_probe)
 
     DTYPE_LABEL = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate",
                    "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)",
@@ -462,26 +558,48 @@ def main():
         bytes_per_launch = (4.0 if dtype in ("f32", "x3") else 2.0) * G * n_loc   # X read once per sweep (counts: ONE bf16 plane in split mode)
         ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        tr = pmc_traffic(args.workload, world, info.k_padded, dtype) if not (args.cells or args.genes) else None
+        # the kernel that actually ran: the x3 sweeps take the 16x16x32 form (x3w) on full-significand data and on wide
+        # models with a padding tile -- alpine_finalize_X decides from a census of X and reports it in alpine_info.x3_wide
+        if mf:
+            kname, kdesc = "stream_gemm_kernel", "MFMA f32 32x32x2"
+        elif dtype == "x3" and info.x3_wide:
+            kname, kdesc = "stream_gemm_x3w_kernel", "float32 X split into exact bf16 planes in registers, MFMA bf16 16x16x32"
+        elif dtype == "x3":
+            kname, kdesc = "stream_gemm_x3_kernel", "float32 X split into exact bf16 planes in registers, MFMA bf16 32x32x16"
+        else:
+            kname, kdesc = "stream_gemm_bf16_kernel", "MFMA bf16 32x32x16, k-packed X" + (" with exact plane split" if dtype == "split" else "")
+        fullsig = m.get("x_scale", 1.0) != 1.0
+        tr = pmc_traffic(args.workload, world, info.k_padded, dtype, fullsig, kname) if not (args.cells or args.genes) else None
         return {
-            "kernel": ("stream_gemm_kernel (MFMA f32 32x32x2; XH^T and W^TX sweeps)" if mf else
-                       "stream_gemm_x3_kernel (float32 X split into exact bf16 planes in registers, MFMA bf16 32x32x16; XH^T and W^TX sweeps)" if dtype == "x3" else
-                       "stream_gemm_bf16_kernel (MFMA bf16 32x32x16, k-packed X; XH^T and W^TX sweeps)" +
-                       (" with exact plane split" if dtype == "split" else "")),
+            "kernel": f"{kname} ({kdesc}; XH^T and W^TX sweeps)", "kernel_name": kname,
             "bound": "mfma" if mf else "hbm",
             "achieved": ach_tf if mf else gbps,
             "peak": FP32_MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBPS,
             "unit": "TFLOP/s" if mf else "GB/s",
             "frac": (ach_tf / FP32_MFMA_PEAK_TFLOPS) if mf else gbps / HBM_PEAK_GBPS,
+            # second view of the same measurement: against the streaming-read ceiling MEASURED on this chip with a compute-free
+            # kernel reading the same tiles (tools/xcd_balance.hip / read_bw_tiled.hip), not the 8 TB/s spec
+            "frac_of_read_ceiling": None if mf else gbps / HBM_READ_CEILING_GBPS, "read_ceiling_GBps": None if mf else HBM_READ_CEILING_GBPS,
             "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
             "avg_launch_ms": avg_ms, "launches": launches, "event_stride": m.get("event_stride", 1),     # launches = event-timed launches (every event_stride-th iteration)
             "avg_ms_xht": m["ms_a"] / max(1, m["n_a"]), "avg_ms_wtx": m["ms_b"] / max(1, m["n_b"]),
             "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
             "tflops": ach_tf, "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS,
             "sweeps_share_of_step": ((m["ms_a"] / max(1, m["n_a"]) + m["ms_b"] / max(1, m["n_b"])) / (1e3 * m["dt"] / args.steps)) if m["dt"] > 0 else 0.0,
+            "x3_wide": int(info.x3_wide), "x_multi_plane_fraction": float(info.x_multi_plane_fraction),
+            "accumulation_span_rows": [int(info.span_rows_a), int(info.span_rows_b)],
         }
 
     main_m = measure(args.dtype)
+    cells_by_rank, rccl_version = [n_loc], None
+    if world > 1:
+        cells_by_rank = [None] * world
+        dist.all_gather_object(cells_by_rank, int(n_loc))
+        try:
+            rccl_version = {"libalpine_hip (librccl it is linked against)": _native.comm_version(),
+                            "torch": ".".join(str(v) for v in torch.cuda.nccl.version())}
+        except Exception as e:          # noqa: BLE001 -- informational only
+            rccl_version = f"unavailable ({type(e).__name__}: {e})"
     others = {}
     if world == 1 and not args.no_other_modes and not args.no_loss:
         # the same workload in the other storage modes (not the headline): exact bf16-plane split (float32-grade
@@ -517,7 +635,7 @@ def main():
                 "workload": (f"{args.workload}: {G} genes x {N} cells, K={ku}+{kcov} (K={K}), {len(kcov)} two-level covariates, "
                              f"lam=1e3, alpha_W={wl['alpha_W']}, orth_W={wl['orth_W']}, l1_ratio_W={wl['l1_ratio_W']}, KL loss, "
                              f"full batch, loss row every iteration={with_loss}; X ~ Poisson(Gamma(0.3)xGamma(0.3)), mean~1"),
-                "cells_per_gpu": n_loc, "k_padded": info.k_padded, "split_xht": info.split_a, "split_wtx": info.split_b,
+                "cells_per_gpu": n_loc, "cells_per_gpu_by_rank": cells_by_rank, "k_padded": info.k_padded, "split_xht": info.split_a, "split_wtx": info.split_b,
                 "grid_xht": info.grid_a, "grid_wtx": info.grid_b, "device_GiB": round(info.device_bytes / 2**30, 2),
                 "parallelism": f"cells/{world}",
                 "x_scale": args.x_scale,      # 1.0 = the spec'd Poisson counts; throughput is value-dependent on this chip
@@ -526,14 +644,17 @@ def main():
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
             "allreduce": ({"avg_ms_on_rank0": main_m["ar_ms"], "bytes": int(info.reduce_block_floats) * 4,
                            "carrier": comm_state["carrier"], "fallback_note": comm_state["note"],
-                           "note": "hipEvents on the ctx stream around the all-reduce: transfer + wait for the slowest rank"}
+                           "note": "avg_ms_on_rank0: hipEvents on the ctx stream around the all-reduce inside the timed loop (transfer + "
+                                   "wait for the slowest rank); first_call_ms / standalone_ms: host-timed before the loop, see probe_allreduce",
+                           **(main_m["ar_probe"] or {})}
                           if world > 1 else None),
+            "rccl_version": rccl_version,
             "updates_only_iterations_per_s": (args.steps / main_m["dt_noloss"]) if main_m.get("dt_noloss") else None,
             "setup_s": main_m["t_gen"],
             "other_modes": others or None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_cells, N)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_cells, N, dev=dev, warmup_budget_s=args.cpu_warmup_budget)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -17,15 +17,22 @@
  * per covariate float32 Y_i[C_i][N]; float32 W0[G][K]; float32 H0[K][N]; per covariate float32 B0_i[C_i][k_i].
  * result.bin: int32 n_loss_rows; float64 losses[n][C+2]; float32 W[G][K]; float32 H[K][N]; per covariate B_i.
  * tests/test_c_abi_example.py writes the problem from a golden case and checks the result against the reference. */
+#ifndef _DEFAULT_SOURCE
+#define _DEFAULT_SOURCE
+#endif
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 #include "alpine_hip.h"
 
 #define MAXC 16
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 static void die(const char* what, alpine_ctx* ctx)
 {
@@ -203,13 +210,32 @@ int main(int argc, char** argv)
         if (pids[r] < 0) { perror("fork"); return 2; }
         if (pids[r] == 0) _exit(run_shard(argv[3], argv[4], r, R, r % D));
     }
-    int bad = 0;
-    for (int r = 0; r < R; ++r) {
+    /* Reap the workers in the order they END.  A rank that dies before ncclCommInitRank would leave its peers blocked in the
+     * communicator set-up for ever: as soon as one worker fails (or the deadline FIT_C_TIMEOUT_S, default 1800 s, passes) the
+     * remaining ones -- only the pids forked above -- are killed and the run fails. */
+    const char* to = getenv("FIT_C_TIMEOUT_S");
+    const double deadline = now_s() + (to && atof(to) > 0 ? atof(to) : 1800.0);
+    int bad = 0, left = R;
+    while (left > 0) {
         int st = 0;
-        if (waitpid(pids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-            fprintf(stderr, "fit_c: rank %d failed\n", r);
-            bad = 1;
+        const pid_t p = waitpid(-1, &st, WNOHANG);
+        if (p == 0) {
+            if (now_s() > deadline) { fprintf(stderr, "fit_c: workers still running at the deadline\n"); bad = 1; break; }
+            struct timespec ts = {0, 20 * 1000 * 1000};
+            nanosleep(&ts, NULL);
+            continue;
         }
+        if (p < 0) { perror("waitpid"); bad = 1; break; }
+        for (int r = 0; r < R; ++r) if (pids[r] == p) {
+            pids[r] = -1; --left;
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "fit_c: rank %d failed\n", r); bad = 1; }
+        }
+        if (bad) break;
     }
-    return bad ? 1 : splice(argv[3], argv[4], R);
+    if (bad) {
+        for (int r = 0; r < R; ++r) if (pids[r] > 0) kill(pids[r], SIGKILL);
+        for (int r = 0; r < R; ++r) if (pids[r] > 0) waitpid(pids[r], NULL, 0);
+        return 1;
+    }
+    return splice(argv[3], argv[4], R);
 }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALPINE_HIP_ABI_VERSION 4
+#define ALPINE_HIP_ABI_VERSION 5
 
 typedef struct alpine_ctx alpine_ctx;
 
@@ -72,6 +72,8 @@ enum {
     ALPINE_FLAG_X3_PRODUCTS = 16
 };
 enum { ALPINE_X_CELLS_BY_GENES = 0, ALPINE_X_GENES_BY_CELLS = 1 };
+/* longest run of contraction rows (cells in the XH^T sweep, genes in the W^TX sweep) that one float32 accumulator covers */
+#define ALPINE_MAX_ACCUMULATION_ROWS 16384
 
 /* Constructor arguments of ALPINE (main.py:47-61) plus the shard geometry. */
 typedef struct {
@@ -89,7 +91,12 @@ typedef struct {
     double l1_ratio_W;              /* main.py:54 */
     double eps;                     /* main.py:59 */
     int32_t loss_type;              /* ALPINE_LOSS_*           (main.py:57) */
-    int32_t split_a;                /* XH^T sweep: ~partial pieces per 512-wide tile; 0 = one equal span per resident workgroup */
+    int32_t split_a;                /* XH^T sweep: 0 (default) = the library's own work division: one equal share of the
+                                       (tile, row) space per resident workgroup.  n > 0 (a test / diagnostic knob) = about n
+                                       workgroups per tile instead.  Either way a share is cut into spans of at most
+                                       ALPINE_MAX_ACCUMULATION_ROWS contraction rows, each accumulated in float32 on its own
+                                       and summed with the others in float64, so the knob changes the launch structure and
+                                       the summation order but NOT the accuracy class (tests/test_gpu_float64_arbiter.py). */
     int32_t split_b;                /* W^TX sweep: same */
     int32_t flags;                  /* ALPINE_FLAG_* */
     void* stream;                   /* hipStream_t to enqueue on, NULL = the library creates one */
@@ -112,6 +119,8 @@ typedef struct {
     double x_multi_plane_fraction;  /* fraction of the elements of X that are not exactly one bf16 plane (float32 storage; after alpine_finalize_X) */
     int32_t x3_wide;                /* 1: the x3 sweeps run on v_mfma_f32_16x16x32_bf16 (full-significand data), 0: on 32x32x16 (count-like data) */
     int32_t reserved;
+    int32_t span_rows_a, span_rows_b;                      /* contraction rows one float32 accumulator chain covers (<= ALPINE_MAX_ACCUMULATION_ROWS) */
+    int32_t spans_per_workgroup_a, spans_per_workgroup_b;  /* accumulator restarts + 1 of a sweep workgroup (1 at BASELINE config 3) */
 } alpine_info;
 
 /* Number of floats in the per-iteration reduce block for a configuration (so a caller can allocate
@@ -180,6 +189,8 @@ int alpine_reduce_block_hht(alpine_ctx* ctx, int64_t* offset_floats, int64_t* n_
 #define ALPINE_COMM_ID_BYTES 128
 int alpine_comm_get_unique_id(void* id_out /* ALPINE_COMM_ID_BYTES bytes */);
 int alpine_comm_init_rank(alpine_ctx* ctx, const void* id, int nranks, int rank);
+/* ncclGetVersion of the librccl this library is linked against, as one integer (e.g. 22203); for run reports. */
+int alpine_comm_version(int* version_out);
 int alpine_comm_destroy(alpine_ctx* ctx);
 int alpine_comm_all_reduce(alpine_ctx* ctx, int64_t offset_floats, int64_t n_floats);
 /* alpine_iter_begin + [all-reduce when a communicator is attached] + alpine_iter_end(update). */

@@ -2,8 +2,8 @@
 regularisers on) for a few iterations on the GPU in every float32-grade sweep mode against the oracle's fused iteration
 run in FLOAT64 on the host from the same initial factors (the float32 CPU oracle beside it, for scale).
 
-Not collected by pytest (32 GB of float64 X on the host, ~1e12 flops per float64 iteration): the committed full-size
-tests check size-independent properties instead (tests/test_gpu_fullsize.py).  Usage:
+By hand at cfg3 (32 GB of float64 X on the host, ~1e12 flops per float64 iteration); the cfg2-size cut (20 000 x 50 000,
+3 iterations: 8 GB, seconds) is collected by pytest: tests/test_gpu_float64_arbiter.py calls compare().  Usage:
 
     python tests/fullsize_vs_float64.py [--workload cfg3] [--iters 3] [--cells N] [--x-scale 1.0] [--out file.json]
 
@@ -26,18 +26,13 @@ from _golden import rel_fro                        # noqa: E402
 from oracle import alpine_oracle as orc            # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--cells", type=int, default=0, help="0 = the workload's own (cfg4: 1 000 000 -- pass its per-GPU share, 125000)")
-    ap.add_argument("--x-scale", type=float, default=1.0)
-    ap.add_argument("--out", default=None)
-    a = ap.parse_args()
+def compare(workload="cfg3", iters=3, cells=0, x_scale=1.0, modes=None, with_float32_oracle=True, log=print):
+    """Run `iters` iterations of `workload` on the GPU in every mode of `modes` and in float64 on the host from the same
+    initial factors; returns {"workload", "iters", "cpu_seconds", "float64_loss_rows", "vs_float64": {name: errors}}."""
     from alpine_amd import _native
     from alpine_amd.datasets import synth_counts_device_chunks
-    wl = dict(bench.WORKLOADS[a.workload])
-    G, N, ku, kcov = wl["genes"], a.cells or wl["cells"], wl["ku"], wl["kcov"]
+    wl = dict(bench.WORKLOADS[workload])
+    G, N, ku, kcov = wl["genes"], cells or wl["cells"], wl["ku"], wl["kcov"]
     levels, lam = [2] * len(kcov), [1e3] * len(kcov)
     dev = torch.device("cuda", 0)
     p = orc.OracleParams(n_components=ku, n_covariate_components=kcov, lam=lam, orth_W=wl["orth_W"], alpha_W=wl["alpha_W"],
@@ -48,16 +43,20 @@ def main():
     t0 = time.perf_counter()
     X = np.empty((N, G), dtype=np.float32)
     for off, chunk in synth_counts_device_chunks(N, G, rank=ku, seed=0, device=dev, chunk_cells=8192):
-        if a.x_scale != 1.0:
-            chunk = chunk * a.x_scale
+        if x_scale != 1.0:
+            chunk = chunk * x_scale
         X[off:off + chunk.shape[0]] = chunk.cpu().numpy()
-    print(f"X {X.shape} generated in {time.perf_counter() - t0:.1f} s; mean {float(X[:4096].mean()):.3f}", flush=True)
+    log(f"X {X.shape} generated in {time.perf_counter() - t0:.1f} s; mean {float(X[:4096].mean()):.3f}")
 
     s32 = orc.init_factors(p, np.ascontiguousarray(X.T), [y.T for y in Ys])
     W0, H0, B0 = s32.W.numpy().copy(), s32.H.numpy().copy(), [b.numpy().copy() for b in s32.Bs]
+    if not with_float32_oracle:
+        s32 = None
 
-    res = {"workload": f"{a.workload}: {G} genes x {N} cells, K={ku}+{kcov}, x_scale={a.x_scale}", "iters": a.iters, "modes": {}}
-    for mode in ("x3", "f32") + (("split",) if a.x_scale == 1.0 else ()):
+    if modes is None:
+        modes = ("x3", "f32") + (("split",) if x_scale == 1.0 else ())
+    res = {"workload": f"{workload}: {G} genes x {N} cells, K={ku}+{kcov}, x_scale={x_scale}", "iters": iters, "modes": {}}
+    for mode in modes:
         eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=levels, lam=lam,
                                   orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype=mode)
         for c0 in range(0, N, 16384):
@@ -66,16 +65,18 @@ def main():
         for i, y in enumerate(Ys):
             eng.upload_Y(i, y)
         eng.set_factors(W0, H0, B0)
-        eng.run(a.iters, with_loss=True)
+        eng.run(iters, with_loss=True)
         W, H, Bs = eng.get_factors()
         res["modes"][mode] = dict(W=W, H=H, Bs=Bs, losses=eng.losses(), x3_wide=int(eng.info().x3_wide))
         eng.close()
-        print(f"GPU {mode}: done", flush=True)
+        log(f"GPU {mode}: done")
 
-    t0 = time.perf_counter()
-    orc.fit_fused(p, s32, a.iters, with_loss=True)
-    t32 = time.perf_counter() - t0
-    print(f"float32 CPU oracle: {a.iters} iterations in {t32:.1f} s", flush=True)
+    t32 = None
+    if s32 is not None:
+        t0 = time.perf_counter()
+        orc.fit_fused(p, s32, iters, with_loss=True)
+        t32 = time.perf_counter() - t0
+        log(f"float32 CPU oracle: {iters} iterations in {t32:.1f} s")
 
     # float64 arbiter (the oracle's fused iteration with every tensor in float64)
     t0 = time.perf_counter()
@@ -85,15 +86,16 @@ def main():
         s64 = orc.OracleState(torch.tensor(X.T, dtype=torch.float64), [torch.tensor(y, dtype=torch.float64) for y in Ys],
                               torch.tensor(W0, dtype=torch.float64), torch.tensor(H0, dtype=torch.float64),
                               [torch.tensor(b, dtype=torch.float64) for b in B0])
-        orc.fit_fused(p, s64, a.iters, with_loss=True)
+        del X
+        orc.fit_fused(p, s64, iters, with_loss=True)
     finally:
         torch.set_default_dtype(old)
     t64 = time.perf_counter() - t0
-    print(f"float64 CPU run: {a.iters} iterations in {t64:.1f} s", flush=True)
+    log(f"float64 CPU run: {iters} iterations in {t64:.1f} s")
     W64, H64, B64 = s64.W.numpy(), s64.H.numpy(), [b.numpy() for b in s64.Bs]
     L64 = np.array(s64.losses)
 
-    out = {"workload": res["workload"], "iters": a.iters, "cpu_seconds": {"float32_oracle": t32, "float64": t64},
+    out = {"workload": res["workload"], "iters": iters, "cpu_seconds": {"float32_oracle": t32, "float64": t64},
            "float64_loss_rows": L64.tolist(), "vs_float64": {}}
 
     def row(name, W, H, Bs, L):
@@ -101,12 +103,24 @@ def main():
                  loss_total_rel=float(np.max(np.abs(L[:, 0] - L64[:, 0]) / np.abs(L64[:, 0]))),
                  loss_recon_rel=float(np.max(np.abs(L[:, 1] - L64[:, 1]) / np.abs(L64[:, 1]))))
         out["vs_float64"][name] = d
-        print(f"{name:>22}: W {d['W']:.2e}  H {d['H']:.2e}  B {['%.1e' % b for b in d['B']]}  loss rows: total {d['loss_total_rel']:.1e} recon {d['loss_recon_rel']:.1e}",
-              flush=True)
+        log(f"{name:>22}: W {d['W']:.2e}  H {d['H']:.2e}  B {['%.1e' % b for b in d['B']]}  loss rows: total {d['loss_total_rel']:.1e} recon {d['loss_recon_rel']:.1e}")
 
-    row("float32 CPU oracle", s32.W.numpy(), s32.H.numpy(), [b.numpy() for b in s32.Bs], np.array(s32.losses))
+    if s32 is not None:
+        row("float32 CPU oracle", s32.W.numpy(), s32.H.numpy(), [b.numpy() for b in s32.Bs], np.array(s32.losses))
     for mode, r in res["modes"].items():
         row(f"GPU {mode}" + (" (x3w)" if r["x3_wide"] else ""), r["W"], r["H"], r["Bs"], r["losses"])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--cells", type=int, default=0, help="0 = the workload's own (cfg4: 1 000 000 -- pass its per-GPU share, 125000)")
+    ap.add_argument("--x-scale", type=float, default=1.0)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    out = compare(a.workload, a.iters, a.cells, a.x_scale, log=lambda m: print(m, flush=True))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(out, open(a.out, "w"), indent=1)

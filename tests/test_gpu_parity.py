@@ -781,7 +781,7 @@ def test_fit_uploads_X_once_and_keeps_it_for_compute_loss_and_transform(monkeypa
         return real(self, X, *a, **kw)
     monkeypatch.setattr(nat.NativeShard, "upload_X_host", counting)
     ad = MiniAnnData(c.X.copy(), c.obs.copy())
-    m = ALPINE(device="cuda:0", **c.params).fit(ad, covariate_keys=c.keys, max_iter=None)
+    m = ALPINE(device="cuda:0", keep_resident=True, **c.params).fit(ad, covariate_keys=c.keys, max_iter=None)
     n_fit = len(uploads)
     assert n_fit == 1 and len(m.loss_history) == m.max_iter           # one chunk, one upload -- warm-up included
     loss = m.compute_loss(ad)
@@ -793,7 +793,7 @@ def test_fit_uploads_X_once_and_keeps_it_for_compute_loss_and_transform(monkeypa
     Ht = np.array(ad.obsm["ALPINE_embedding"])
     # the same calls on a model that does not keep its engine
     ad2 = MiniAnnData(c.X.copy(), c.obs.copy())
-    m2 = ALPINE(device="cuda:0", keep_resident=False, **c.params).fit(ad2, covariate_keys=c.keys, max_iter=m.max_iter)
+    m2 = ALPINE(device="cuda:0", **c.params).fit(ad2, covariate_keys=c.keys, max_iter=m.max_iter)      # the default: nothing stays in HBM
     assert m2._resident is None and np.array_equal(np.array(ad2.obsm["ALPINE_embedding"]), emb)
     n2 = len(uploads)
     loss2 = m2.compute_loss(ad2)
@@ -803,13 +803,24 @@ def test_fit_uploads_X_once_and_keeps_it_for_compute_loss_and_transform(monkeypa
     assert len(uploads) == n2 + 2                                      # compute_loss and transform each re-upload
     assert abs(loss - loss2) <= 1e-6 * abs(loss2)
     assert rel_fro(Ht, np.array(ad2.obsm["ALPINE_embedding"])) < 1e-6
-    # a different matrix (or an edited one) is never served from the resident copy
-    ad3 = MiniAnnData(c.X.copy(), c.obs.copy())
+    # an in-place edit ANYWHERE in the fitted matrix (here one element of a row that a sampled-rows hash would miss) is seen by
+    # the whole-array checksum: the stale HBM copy is released and the call uploads the edited matrix
+    assert m._resident is not None
+    ad.X[1, 3] += 1.0
     before = len(uploads)
-    m.transform(ad3, n_iter=2)
-    assert len(uploads) == before + 1
-    m.release()
-    assert m._resident is None
+    loss_edit = m.compute_loss(ad)
+    assert len(uploads) == before + 1 and m._resident is None
+    ad_edit = MiniAnnData(ad.X.copy(), c.obs.copy())
+    ad_edit.obsm.update(ad.obsm)
+    ad_edit.varm.update(ad.varm)
+    assert abs(loss_edit - m.compute_loss(ad_edit)) <= 1e-6 * abs(loss_edit)          # same factors, fresh upload of the same edited X
+    # ... and a different matrix object is never served from a resident copy either
+    m3 = ALPINE(device="cuda:0", keep_resident=True, **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=3)
+    assert m3._resident is not None
+    before = len(uploads)
+    m3.transform(MiniAnnData(c.X.copy(), c.obs.copy()), n_iter=2)
+    assert len(uploads) == before + 1 and m3._resident is None
+    m3.release()
 
 
 def test_trace_form_loss_cancellation_bound_on_a_near_exact_fit():

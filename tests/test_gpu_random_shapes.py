@@ -162,3 +162,74 @@ def test_many_label_levels_vs_oracle(loss_type):
     want = np.array(s.losses)
     np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=1e-4)
     np.testing.assert_allclose(losses[:, 2:], want[:, 2:], rtol=2e-3, atol=1e-6 * N)
+
+
+def _fit_vs_oracle(seed, G, N, Ku, ks, levels, loss, iters, env=None, monkeypatch=None, reg=False):
+    """`iters` MU iterations of a random problem through the C ABI against the oracle's fused iteration (shared by the LDS
+    budget and wide-guidance cases below)."""
+    from alpine_amd import _native as nat
+    rng = np.random.default_rng(seed)
+    X = rng.gamma(0.4, 2.5, size=(N, G)).astype(np.float32)
+    Ys = []
+    for C in levels:
+        Y = np.zeros((N, C), dtype=np.float32)
+        Y[np.arange(N), rng.integers(0, C, size=N)] = 1.0
+        Ys.append(Y)
+    p = orc.OracleParams(n_components=Ku, n_covariate_components=list(ks), lam=[float(rng.choice([1.0, 30.0, 1e3])) for _ in ks],
+                         orth_W=0.1 if reg else 0.0, alpha_W=0.6 if reg else 0.0, l1_ratio_W=0.3 if reg else 0.0,
+                         loss_type=loss, random_state=seed)
+    s = orc.init_factors(p, np.ascontiguousarray(X.T), Ys)
+    W0, H0, B0 = s.W.numpy().copy(), s.H.numpy().copy(), [b.numpy().copy() for b in s.Bs]
+    orc.fit_fused(p, s, iters, with_loss=True)
+    if env:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+    out = {}
+    for mode in ("x3", "f32"):
+        eng = nat.NativeShard(n_genes=G, n_cells=N, n_components=Ku, cov_components=list(ks), cov_levels=list(levels), lam=p.lam,
+                              orth_W=p.orth_W, alpha_W=p.alpha_W, l1_ratio_W=p.l1_ratio_W, eps=p.eps, loss_type=loss, x_dtype=mode)
+        try:
+            eng.upload_X_host(X)
+            eng.finalize_X()
+            for i, y in enumerate(Ys):
+                eng.upload_Y(i, np.ascontiguousarray(y.T))
+            eng.set_factors(W0, H0, B0)
+            eng.run(iters, with_loss=True)
+            W, H, Bs = eng.get_factors()
+            losses = eng.losses()
+        finally:
+            eng.close()
+        tol = 2e-5 * max(1, iters)
+        assert rel_fro(W, s.W.numpy()) < tol and rel_fro(H, s.H.numpy()) < tol, (mode, rel_fro(W, s.W.numpy()), rel_fro(H, s.H.numpy()))
+        for b, bo in zip(Bs, s.Bs):
+            assert rel_fro(b, bo.numpy()) < 5 * tol, mode
+        want = np.array(s.losses)
+        np.testing.assert_allclose(losses[:, :2], want[:, :2], rtol=2e-4, err_msg=mode)
+        np.testing.assert_allclose(losses[:, 2:], want[:, 2:], rtol=2e-3, atol=1e-6 * N, err_msg=mode)
+        out[mode] = (W, H, losses)
+    return out
+
+
+@pytest.mark.parametrize("ks,levels,Ku", [
+    ([10, 3], [30, 4], 90),        # K = 103 (KT = 4), 34 rows of Y (> 32: Y stays in global memory), k = 10 x 16 classes of scratch:
+                                   # 134 KB of update + 2 x 12 KB of statistics scratch > 160 KB -> the tail is dropped
+    ([60], [2], 50),               # K = 110, one covariate of k = 60: Y copy + tail scratch push the total to 166 KB -> Y copy dropped first
+    ([64], [40], 20),              # K = 84 (KT = 3), k = 64 with 40 levels: the largest statistics scratch the limits allow
+])
+def test_h_update_lds_budget_fallbacks(ks, levels, Ku):
+    """the fused H update's optional LDS (Y copy, tail scratch) on top of ~134 KB at K > 96 could exceed the CU's
+    160 KB for configurations _check_supported accepts; the launch failed and fit() raised.  launch_h_update now drops the Y
+    copy and / or the tail when the total does not fit (same results through phase1_open_kernel)."""
+    _fit_vs_oracle(101 + len(levels), G=150, N=700, Ku=Ku, ks=ks, levels=levels, loss="kl-divergence", iters=3)
+    _fit_vs_oracle(201 + len(levels), G=150, N=700, Ku=Ku, ks=ks, levels=levels, loss="frobenius", iters=3, reg=True)
+
+
+def test_forced_small_lds_limit_equals_the_default_path(monkeypatch):
+    """The same fall-back forced on a small model (ALPINE_HIP_LDS_LIMIT, read once in alpine_create): without the fused tail
+    (H H^T partials and statistics from phase1_open_kernel: another summation order) the factors agree to rounding."""
+    a = _fit_vs_oracle(77, G=130, N=600, Ku=20, ks=[3, 2], levels=[3, 2], loss="kl-divergence", iters=4)
+    b = _fit_vs_oracle(77, G=130, N=600, Ku=20, ks=[3, 2], levels=[3, 2], loss="kl-divergence", iters=4,
+                       env={"ALPINE_HIP_LDS_LIMIT": "26000"}, monkeypatch=monkeypatch)
+    for mode in ("x3", "f32"):
+        assert rel_fro(a[mode][0], b[mode][0]) < 2e-6 and rel_fro(a[mode][1], b[mode][1]) < 2e-6
+        assert not (np.array_equal(a[mode][0], b[mode][0]) and np.array_equal(a[mode][1], b[mode][1]))      # the knob did change the launch structure

@@ -20,15 +20,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, out_dir, local=False, shard_comm="auto"):
+def _worker(rank, world, port, case_name, out_dir, local=False, shard_comm="auto", device_per_rank=False):
     # (fit_kwargs of the golden case -- batch_size / sampling_method -- are passed through: sharded mini-batches)
+    # device_per_rank: rank r drives cuda:r and torch.distributed runs on the nccl (= RCCL) backend -- the production layout
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev_i = rank if device_per_rank else 0
+    torch.cuda.set_device(dev_i)
+    if device_per_rank:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_i))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from _golden import load_case
     from alpine_amd import ALPINE, MiniAnnData
     c = load_case(case_name)
@@ -37,7 +42,7 @@ def _worker(rank, world, port, case_name, out_dir, local=False, shard_comm="auto
         n = c.X.shape[0]
         cut = [0, n // 3 + 1, n]
         adata = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
-        m = ALPINE(device="cuda:0", shard_cells="local", shard_comm=shard_comm, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+        m = ALPINE(device=f"cuda:{dev_i}", shard_cells="local", shard_comm=shard_comm, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
         assert adata.obsm["ALPINE_embedding"].shape[0] == cut[rank + 1] - cut[rank]
         if c.transform_iters:                      # transform of the rank's own cells right after the fit
             a_t = MiniAnnData(c.X[cut[rank]:cut[rank + 1]].copy(), c.obs.iloc[cut[rank]:cut[rank + 1]].reset_index(drop=True))
@@ -46,9 +51,10 @@ def _worker(rank, world, port, case_name, out_dir, local=False, shard_comm="auto
                     np.concatenate([np.asarray(a_t.obsm[k]).T for k in c.keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0))
     else:
         adata = MiniAnnData(c.X.copy(), c.obs.copy())
-        m = ALPINE(device="cuda:0", shard_cells=True, shard_comm=shard_comm, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+        m = ALPINE(device=f"cuda:{dev_i}", shard_cells=True, shard_comm=shard_comm, **c.params).fit(adata, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=np.concatenate(m.matrices["Ws"], axis=1),
              H=np.concatenate(m.matrices["Hs"], axis=0), losses=m.loss_history.to_numpy(), comm=np.array(m.shard_comm_used),
+             comm_note=np.array(str(m.shard_comm_note)),
              **{f"B{i}": b for i, b in enumerate(m.matrices["Bs"])})
     dist.barrier()
     dist.destroy_process_group()

@@ -19,6 +19,7 @@ static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced)     // s
     const int64_t total = (int64_t)g.nft * R;
     int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
     want = std::max<int64_t>(1, std::min<int64_t>(want, total / SG_ROW_ALIGN));
+    g.sub = 1;                                 // one span per workgroup here (the library caps spans at SG_MAX_CHAIN rows)
     g.L = (int)round_up((total + want - 1) / want, SG_ROW_ALIGN);
     g.nwg = (int)((total + g.L - 1) / g.L);
     g.maxp = (int)((g.L + R - 1) / R) + 1;
