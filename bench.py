@@ -222,7 +222,7 @@ def pmc_traffic(workload: str, world: int, kp: int, dtype: str = "f32", fullsig:
         try:
             d = json.load(open(f))
             m = re.search(r"<(\d+)", d.get("kernel", ""))
-            same_kernel = not kernel_name or d.get("kernel", "").split("<")[0].strip() == kernel_name
+            same_kernel = not kernel_name or d.get("kernel", "").split("<")[0].strip().split("::")[-1] == kernel_name
             if m and int(m.group(1)) == kp // 32 and same_kernel:
                 best = {"bytes_per_launch": d["traffic_bytes_per_launch"], "over_algorithmic": d["traffic_over_algorithmic"],
                         "kernel": d.get("kernel"), "source": os.path.relpath(f, REPO)}
