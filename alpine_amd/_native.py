@@ -29,7 +29,7 @@ EXPORTS = [
     "alpine_upload_X_host", "alpine_upload_X_device", "alpine_finalize_X", "alpine_upload_Y",
     "alpine_set_factors", "alpine_get_factors", "alpine_iter_begin", "alpine_iter_end", "alpine_reduce_block",
     "alpine_als_begin", "alpine_als_group_begin", "alpine_als_group_end", "alpine_reduce_block_hht", "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
-    "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_get_kernel_time", "alpine_read_buffer",
+    "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_debug_set_xcd_bias", "alpine_debug_run_graph", "alpine_get_kernel_time", "alpine_read_buffer",
     "alpine_comm_get_unique_id", "alpine_comm_version", "alpine_comm_init_rank", "alpine_comm_destroy", "alpine_comm_all_reduce", "alpine_iter",
 ]
 
@@ -56,6 +56,7 @@ class AlpineInfo(C.Structure):
         ("x_multi_plane_fraction", C.c_double), ("x3_wide", C.c_int32), ("reserved", C.c_int32),
         ("span_rows_a", C.c_int32), ("span_rows_b", C.c_int32),
         ("spans_per_workgroup_a", C.c_int32), ("spans_per_workgroup_b", C.c_int32),
+        ("xcd_bias_per_mille", C.c_int32), ("xcc_of_workgroup0", C.c_int32),
     ]
 
 
@@ -113,6 +114,8 @@ def load() -> C.CDLL:
     lib.alpine_synchronize.argtypes = [p]
     lib.alpine_eval_recon_direct.argtypes = [p, C.POINTER(C.c_double)]
     lib.alpine_set_profiling.argtypes = [p, i32]
+    lib.alpine_debug_set_xcd_bias.argtypes = [p, i32]
+    lib.alpine_debug_run_graph.argtypes = [p, i32]
     lib.alpine_get_kernel_time.argtypes = [p, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.alpine_read_buffer.argtypes = [p, i32, i64, i64, p]
     lib.alpine_comm_get_unique_id.argtypes = [p]
@@ -331,6 +334,12 @@ class NativeShard:
     def set_profiling(self, on):
         """False / 0 = off, True / 1 = events around every sweep and all-reduce, n > 1 = every n-th iteration only."""
         self._chk(self._lib.alpine_set_profiling(self._h, int(on)))
+
+    def debug_set_xcd_bias(self, per_mille: int):
+        self._chk(self._lib.alpine_debug_set_xcd_bias(self._h, int(per_mille)))
+
+    def debug_run_graph(self, n_pairs: int):
+        self._chk(self._lib.alpine_debug_run_graph(self._h, int(n_pairs)))
 
     def kernel_time(self, which: int):
         ms, n = C.c_double(), C.c_int64()

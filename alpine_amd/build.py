@@ -12,6 +12,8 @@ DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HE
 LIB = os.path.join(HERE, "libalpine_hip.so")
 # diagnostics build (-DALPINE_DIAGNOSTICS): the timing-only ablations of tools/ (wrong results by design) exist only here
 LIB_DIAG = os.path.join(HERE, "libalpine_hip_diag.so")
+# throwaway build with in-kernel time stamps (-DALPINE_STAMPS) for tools/stamps.py
+LIB_STAMPS = os.path.join(HERE, "libalpine_hip_stamps.so")
 ROCM_LIB = "/opt/rocm/lib"
 
 
@@ -29,10 +31,12 @@ def is_stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=(), diagnostics: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), diagnostics: bool = False, stamps: bool = False) -> str:
     """hipcc -> libalpine_hip.so (links libamdhip64 and librccl; in a torch process both resolve to the copies torch has
     already loaded, same sonames).  diagnostics=True builds libalpine_hip_diag.so with the ablation knobs compiled in."""
-    lib = LIB_DIAG if diagnostics else LIB
+    lib = LIB_STAMPS if stamps else (LIB_DIAG if diagnostics else LIB)
+    if stamps:
+        extra_flags = tuple(extra_flags) + ("-DALPINE_STAMPS",)
     if not force and not is_stale(lib):
         return lib
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -49,4 +53,4 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), di
 
 if __name__ == "__main__":
     import sys
-    print(build_library(force="--force" in sys.argv, verbose=True, diagnostics="--diag" in sys.argv))
+    print(build_library(force="--force" in sys.argv, verbose=True, diagnostics="--diag" in sys.argv, stamps="--stamps" in sys.argv))

@@ -116,6 +116,13 @@ struct alpine_ctx {
     int comm_ranks = 1, comm_rank = 0;
     bool transform_only = false;
     bool use_als = false;
+    bool no_guided_mfma = false;      // env ALPINE_HIP_GUIDED=scalar: the per-(covariate, class) scalar form of the guided terms instead of the MFMA products (A/B)
+    GuidedRow* rowtab = nullptr;      // [32] stacked rows of Y -> covariate (guided terms on the MFMA, see GuidedRow)
+    bool xcd_bias_auto = true;        // no ALPINE_HIP_XCD_BIAS in the environment: decided by the placement probe (create_impl)
+    int xcc_of_wg0 = -1;              // placement probe (alpine_finalize_X): XCC id that workgroup 0 of a sweep launch ran on
+    int* xcc_dev = nullptr;           // ... written here by that launch
+    bool probe_placement = false;
+    int xcd_bias_pm = 0;              // env ALPINE_HIP_XCD_BIAS (per mille): span length of even workgroups +bias, odd -bias (see SweepGeom::dL)
     bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     int x3_variant = -1;              // env ALPINE_HIP_X3_VARIANT: 0 = 32x32x16 MFMA, 2 = 16x16x32 (x3w), unset = chosen from the data
@@ -208,18 +215,18 @@ static int geometry(const alpine_config* cfg, Geometry* g, std::string* why)
     if (cfg->n_components <= 0) { *why = "n_components must be greater than 0."; return -1; }
     if (cfg->n_covariates < 0 || cfg->n_covariates > MAX_COV) { *why = "n_covariates out of range (0..16)"; return -1; }
     if (cfg->n_covariates > 0 && (!cfg->cov_components || !cfg->cov_levels || !cfg->lam)) { *why = "covariate arrays are NULL"; return -1; }
-    int K = cfg->n_components, guided = 0, nstat = 0, nB = 0, nY = 0;
+    int K = cfg->n_components, nstat = 0, nB = 0, nY = 0;
     for (int i = 0; i < cfg->n_covariates; ++i) {
         const int k = cfg->cov_components[i], C = cfg->cov_levels[i];
-        if (k <= 0 || k > MAX_COV_K) { *why = "each covariate needs 1..64 guided components in this build"; return -1; }
+        // k = 0 is the reference's "covariate without guided components" (main.py:335 rejects only n < 0): it only adds its loss column
+        if (k < 0 || k > MAX_COV_K) { *why = "a covariate may have 0..64 guided components in this build"; return -1; }
         if (C <= 0) { *why = "each covariate needs at least one level"; return -1; }
         if (!(cfg->lam[i] >= 0)) { *why = "Each element in lam must be a non-negative float."; return -1; }
-        K += k; guided += k;
+        K += k;
         nstat += C * k + k + 2;
         nB += C * k;
         nY += C;
     }
-    if (guided > 64) { *why = "the guided components must fit in the first 64 columns (sum k_i <= 64)"; return -1; }
     if (K > 128) { *why = "total components > 128 not supported by this build"; return -1; }
     if (cfg->loss_type != ALPINE_LOSS_KL && cfg->loss_type != ALPINE_LOSS_FROBENIUS) { *why = "loss_type must be one of ['kl-divergence', 'frobenius']."; return -1; }
     if (!(cfg->eps >= 0) || !(cfg->alpha_W >= 0) || !(cfg->orth_W >= 0) || !(cfg->l1_ratio_W >= 0 && cfg->l1_ratio_W <= 1)) { *why = "eps/alpha_W/orth_W must be >= 0 and l1_ratio_W in [0,1]"; return -1; }
@@ -242,28 +249,7 @@ extern "C" int64_t alpine_reduce_block_floats(const alpine_config* cfg)
     return g.red_floats;
 }
 
-// Stream-K geometry of a sweep (see SweepGeom in kernels.hpp): a fixed grid of `slots` workgroups (as many as the
-// chip holds at once), each an equal share of the (tile,row) space.  forced > 0 asks for about `forced` workgroups per
-// tile instead (tests use it to exercise shares that do / do not cross tiles).  A workgroup's share is cut into `sub`
-// equal spans of L <= SG_MAX_CHAIN rows: it restarts its float32 accumulators at every span boundary and writes a piece
-// per span and tile, so the length of an accumulator chain -- and with it the rounding error of a sweep, which has the
-// same sign every iteration because X does not change -- is bounded independently of the shard size (the spans' pieces
-// are summed in float64 by the consumers).  cfg3's shares are 15 4xx-15 6xx rows: sub = 1, nothing changes there.
-static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced, int bf = SG_BLOCK_F)
-{
-    SweepGeom g{};
-    g.F = (int)F; g.R = (int)R; g.bf = bf;
-    g.nft = (int)((F + bf - 1) / bf);
-    const int64_t total = (int64_t)g.nft * R;
-    int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
-    want = std::max<int64_t>(1, std::min<int64_t>(want, total / SG_ROW_ALIGN));
-    const int64_t share = round_up((total + want - 1) / want, SG_ROW_ALIGN);         // rows per workgroup
-    g.sub = (int)((share + SG_MAX_CHAIN - 1) / SG_MAX_CHAIN);
-    g.L = (int)round_up((share + g.sub - 1) / g.sub, SG_ROW_ALIGN);
-    g.nwg = (int)((total + g.L - 1) / g.L);
-    g.maxp = (int)((g.L + R - 1) / R) + 1;
-    return g;
-}
+static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced, int bf = SG_BLOCK_F, int bias_pm = 0) { return sg_make_geom(F, R, slots, forced, bf, bias_pm); }
 static inline int sweep_grid(const SweepGeom& g) { return (g.nwg + g.sub - 1) / g.sub; }
 
 static int gram_rows_per_wave(int64_t R, int n_cu)
@@ -277,8 +263,8 @@ static int gram_rows_per_wave(int64_t R, int n_cu)
 static void apply_sweep_geometry(alpine_ctx* c, int bf)
 {
     c->sweep_bf = bf;
-    c->geomA = make_geom(c->Gp, c->Np, c->slots, c->split_a_hint, bf);       // XH^T: f = genes, r = cells
-    c->geomB = make_geom(c->Np, c->Gp, c->slots, c->split_b_hint, bf);       // W^TX: f = cells, r = genes
+    c->geomA = make_geom(c->Gp, c->Np, c->slots, c->split_a_hint, bf, c->xcd_bias_pm);       // XH^T: f = genes, r = cells
+    c->geomB = make_geom(c->Np, c->Gp, c->slots, c->split_b_hint, bf, c->xcd_bias_pm);       // W^TX: f = cells, r = genes
     c->full.gA = c->geomA; c->full.gB = c->geomB;
 }
 
@@ -318,6 +304,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->ablate_flush = getenv_is("ALPINE_HIP_ABLATE_FLUSH", '1');
     if (const char* e = std::getenv("ALPINE_HIP_X3_ABLATE")) c->x3_ablate = std::atoi(e);
 #endif
+    if (const char* e = std::getenv("ALPINE_HIP_GUIDED")) c->no_guided_mfma = (std::strcmp(e, "scalar") == 0);
+    if (const char* e = std::getenv("ALPINE_HIP_XCD_BIAS")) { c->xcd_bias_pm = std::max(-200, std::min(200, std::atoi(e))); c->xcd_bias_auto = false; }
     if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
     if (const char* e = std::getenv("ALPINE_HIP_X3_VARIANT")) c->x3_variant = std::atoi(e);
     if (const char* e = std::getenv("ALPINE_HIP_H_UPDATE")) c->h_update_valu = (std::strcmp(e, "valu") == 0);
@@ -338,12 +326,31 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         off += k; boff += C * k; yoff += C; soff += C * k + k + 2;
     }
     c->y_set.assign(c->n_cov, false);
+    {
+        GuidedRow rows[32];
+        for (int r = 0; r < 32; ++r) {
+            rows[r] = GuidedRow{0, 0, 0, 0.f};                          // rows past the last class: no columns
+            for (int i = 0; i < c->n_cov; ++i) {
+                const int rr = r - c->meta.yoff[i];
+                if (rr >= 0 && rr < c->meta.lev[i])
+                    rows[r] = GuidedRow{c->meta.off[i], c->meta.k[i], c->meta.boff[i] + rr * c->meta.k[i],
+                                        c->loss_type == ALPINE_LOSS_KL ? c->meta.lam[i] : c->meta.lam2[i]};
+            }
+        }
+        ALLOC(c, c->xcc_dev, int, 4);
+        ALLOC(c, c->rowtab, GuidedRow, 32);
+        HIPCHK(c, hipMemcpyAsync(c->rowtab, rows, sizeof rows, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
 
     const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
     // sweeps
     // bf16 sweeps with K <= 64: 8-wave workgroups (1024-column tiles, one per CU); everything else 4 waves x 512 columns
     c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;   // A/B of the workgroup shape, same results
-    const int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
+    int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
+    // experiment knob (same results): K <= 32 x3 kernels fit two waves per SIMD (<= 256 registers): ALPINE_HIP_X3_SLOTS=2 gives them
+    // two workgroups per CU -- the one data point available for "would a second wave per SIMD help the memory-bound sweep?"
+    if (c->x3 && c->KT == 1 && getenv_is("ALPINE_HIP_X3_SLOTS", '2')) slots = 2 * c->n_cu;
     c->slots = slots;
     // K <= 64: 1024-column workgroup tiles (a wave owns 256 columns) -- except for small shards on the 32x32x16 form, where the
     // piece traffic (every workgroup flushes bf x KP accumulators whatever the shard size: 67 MB per sweep at 1024 columns,
@@ -359,7 +366,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     // pieces: nwg * maxp tiles of bf x KP floats; mini-batch views have their own geometry (alpine_batch_begin), one per
     // view size.  Sized for every tile width and every view size this ctx may use.
     auto piece_floats = [&](int bf, int64_t* capA, int64_t* capB) {
-        const SweepGeom a = make_geom(Gp, Np, slots, cfg->split_a, bf), b = make_geom(Np, Gp, slots, cfg->split_b, bf);
+        const SweepGeom a = make_geom(Gp, Np, slots, cfg->split_a, bf, c->xcd_bias_pm), b = make_geom(Np, Gp, slots, cfg->split_b, bf, c->xcd_bias_pm);
         int64_t ta = (int64_t)a.nwg * a.maxp, tb = (int64_t)b.nwg * b.maxp;
         if (c->batch_cap > 0) {
             const int64_t Bp_max = round_up(std::min<int64_t>(c->batch_cap, (int64_t)1 << 30), 128);
@@ -368,6 +375,8 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
                 ta = std::max<int64_t>(ta, (int64_t)va.nwg * va.maxp); tb = std::max<int64_t>(tb, (int64_t)vb.nwg * vb.maxp);
             }
         }
+        // (+ a few workgroups: alpine_debug_set_xcd_bias may move the last share's boundary)
+        ta += 4 * (int64_t)a.sub * a.maxp; tb += 4 * (int64_t)b.sub * b.maxp;
         *capA = std::max(*capA, ta * bf * KP); *capB = std::max(*capB, tb * bf * KP);
     };
     const int bf_default = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
@@ -479,7 +488,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->rowtab, c->xcc_dev, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -504,6 +513,7 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     info->reserved = 0;
     info->span_rows_a = c->geomA.L; info->span_rows_b = c->geomB.L;
     info->spans_per_workgroup_a = c->geomA.sub; info->spans_per_workgroup_b = c->geomB.sub;
+    info->xcd_bias_per_mille = c->xcd_bias_pm; info->xcc_of_workgroup0 = c->xcc_of_wg0;
     return 0;
 }
 
@@ -636,6 +646,8 @@ static int sum_f64_partials(alpine_ctx* c, int n, double* out)
     return 0;
 }
 
+static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which);
+
 extern "C" int alpine_finalize_X(alpine_ctx* c)
 {
     if (!c) return ALPINE_ERR_BAD_ARG;
@@ -687,6 +699,27 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
             if (narrow != c->x3_narrow) { c->x3_narrow = narrow; apply_sweep_geometry(c, narrow ? 512 : 1024); c->tail_valid = false; }
         }
     }
+    if (c->xcd_bias_auto && (c->x3 || c->bf16)) {
+        // Placement probe.  The XCDs do not stream the sweeps' access pattern at the same rate: on MI355X the odd XCCs finish a
+        // sweep 6-7 % after the even ones (tools/stamps.py sweep, every box so far), and giving the workgroups that land on them
+        // 4 % shorter spans takes 0.7-1.4 % off an iteration (tools/xcd_bias_sweep.py: one engine, interleaved; the XCDs share
+        // one memory-side limit, so most of the imbalance is NOT recoverable).  Sweep workgroups go to the XCDs round-robin,
+        // workgroup 0 always to the same XCC for this kernel (XCC 7 on every box so far; a grid of small workgroups starts on
+        // XCC 0, so the question is put to the sweep kernel itself): one launch of the W^TX sweep over the resident X with the
+        // (still zero) panel reports where its workgroup 0 ran.  The division itself stays a static function of blockIdx:
+        // results never depend on placement, only this 1 % does.
+        c->probe_placement = true;
+        rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB, 1);
+        c->probe_placement = false;
+        if (rc) return rc;
+        int h = -1;
+        HIPCHK(c, hipMemcpyAsync(&h, c->xcc_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->xcc_of_wg0 = h;
+        const int mag = 40;                                         // per mille; more stops paying (and would push cfg3's spans past the accumulation cap)
+        const int bias = h < 0 ? 0 : ((h & 1) ? -mag : mag);        // workgroup 0 on an odd XCC: the even workgroups are the slow ones
+        if (bias != c->xcd_bias_pm) { c->xcd_bias_pm = bias; apply_sweep_geometry(c, c->sweep_bf); c->tail_valid = false; }
+    }
     c->x_final = true;
     return 0;
 }
@@ -730,6 +763,7 @@ extern "C" int alpine_set_factors(alpine_ctx* c, const float* W, const float* H,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bcur = 0;
     for (int i = 0; i < c->n_cov; ++i) {
+        if (c->cov_lev[i] * c->cov_k[i] == 0) continue;                       // k_i = 0: B_i is C_i x 0
         if (!B[i]) return fail(c, ALPINE_ERR_BAD_ARG, "B[%d] is NULL", i);
         HIPCHK(c, hipMemcpyAsync(c->B[0] + c->meta.boff[i], B[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyHostToDevice, c->stream));
     }
@@ -760,7 +794,7 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
         HIPCHK(c, hipMemcpy2DAsync(H, sizeof(float) * ldH, c->stage, sizeof(float) * c->N, sizeof(float) * c->N, (size_t)K, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    if (B) for (int i = 0; i < c->n_cov; ++i) if (B[i])
+    if (B) for (int i = 0; i < c->n_cov; ++i) if (B[i] && c->cov_lev[i] * c->cov_k[i] > 0)
         HIPCHK(c, hipMemcpyAsync(B[i], c->B[c->bcur] + c->meta.boff[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -818,7 +852,8 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
     }
     const unsigned short* S = which == 0 ? c->Xng16 : c->Xgn16;
     float* pieces = which == 0 ? c->piecesA : c->piecesB;
-#define BF_ARGS S, (which == 0 ? c->x_plane_ng : c->x_plane_gn), panel, p_plane, master, pieces, g
+    int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
+#define BF_ARGS S, (which == 0 ? c->x_plane_ng : c->x_plane_gn), panel, p_plane, master, pieces, g, xcc_out
 #define BF_LAUNCH(NPX, NPP) do { \
         if (g.bf == 8 * SG_WAVE_F) {          /* 8 waves: K <= 64 only (create_impl) */ \
             if (c->KT == 1) hipLaunchKernelGGL((stream_gemm_bf16_kernel<1, NPX, NPP, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
@@ -841,13 +876,14 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
     if (c->x3) {
         SweepGeom gx = g;
+        int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
         if (c->ablate_flush) gx.panel_fixed = 2;
         else if (c->ablate_panel) gx.panel_fixed = 1;
         if (c->x3_wide && !c->x3_ablate) {
             const bool pad_tile = c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
 #define X3W_LAUNCH(KT_, NH_) do { \
-                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); \
-                else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); } while (0)
+                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); \
+                else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); } while (0)
             switch (c->KT) {
                 case 1: if (c->x3_narrow) X3W_LAUNCH(1, 1); else X3W_LAUNCH(1, 2); break;
                 case 2: if (c->x3_narrow) X3W_LAUNCH(2, 1); else X3W_LAUNCH(2, 2); break;
@@ -860,20 +896,20 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         }
         switch (c->KT) {
             case 1:
-                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<1, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out);
                 break;
             case 2:
 #ifdef ALPINE_DIAGNOSTICS
-                if (c->x3_ablate == 1) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
-                if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
-                if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break; }
+                if (c->x3_ablate == 1) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); break; }
+                if (c->x3_ablate == 2) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); break; }
+                if (c->x3_ablate == 3) { hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2, 3>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); break; }
 #endif
-                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
-                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx);
+                if (c->x3_narrow) hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out);
+                else hipLaunchKernelGGL((stream_gemm_x3_kernel<2, 2>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out);
                 break;
-            case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
-            default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx); break;
+            case 3: hipLaunchKernelGGL((stream_gemm_x3_kernel<3, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); break;
+            default: hipLaunchKernelGGL((stream_gemm_x3_kernel<4, 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); break;
         }
         HIPCHK(c, hipGetLastError());
         return 0;
@@ -1012,7 +1048,9 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
     const int KP = c->KP, K = c->K;
     const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
     size_t h_bytes_mfma = sizeof(float) * (KP * KP + ((std::max(1, c->nB) + 3) & ~3) + 4 * 32 * (KP + 4));   // + per-wave transpose scratch
-    if (c->h_update_valu && !c->use_als) {   // reference implementation of the same update on the VALU (A/B and fallback)
+    int guided_total = 0;
+    for (int i = 0; i < c->n_cov; ++i) guided_total += c->cov_k[i];
+    if (c->h_update_valu && !c->use_als && guided_total <= 64) {   // the same update on the VALU (A/B; its guided columns must sit in lanes 0..63)
         const int hblocks = (int)((v.N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
                                                c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
@@ -1026,23 +1064,38 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
         const size_t base = h_bytes_mfma;
         int max_k = 1, max_ct = 1;
         cov_maxima(c, &max_k, &max_ct);
-        auto total_bytes = [&](int ybuf_rows, bool tail_on) {
-            size_t b = base + sizeof(float) * (size_t)ybuf_rows * HS_CELLS;
+        int guided = 0;
+        for (int i = 0; i < c->n_cov; ++i) guided += c->cov_k[i];
+        const int kg = (guided + 7) / 8 * 8;
+        // LDS on top of the update's own, in order of preference (same results in every form, fewer launches / less latency first):
+        //   gm  = guided terms as two small matrix products on the MFMA: needs all of Y's rows in LDS (<= 32)
+        //   y   = the Y copy of the block's cells in LDS (else Y is read from global memory per covariate and class)
+        //   tail = the fused tail (else the next phase 1 runs phase1_open_kernel)
+        auto total_bytes = [&](bool gm, int ybuf_rows, bool tail_on) {
+            size_t b = base + sizeof(float) * (size_t)(gm ? (ybuf_rows + 7) / 8 * 8 : ybuf_rows) * HS_CELLS;
+            if (gm) b += sizeof(GuidedRow) * 32;
             if (tail_on) b += ybuf_rows ? hstats_tail_bytes(max_k, max_ct) : 2 * hstats_group_bytes(max_k, max_ct);
             return b;
         };
-        int ybuf_rows = (c->nYrows > 0 && c->nYrows <= HT_YROWS_MAX) ? c->nYrows : 0;      // Y of a block's cells in LDS
-        if (total_bytes(ybuf_rows, with_tail) > c->lds_max && ybuf_rows && total_bytes(0, with_tail) <= c->lds_max) ybuf_rows = 0;
-        if (total_bytes(ybuf_rows, with_tail) > c->lds_max) { with_tail = false; }
-        if (total_bytes(ybuf_rows, with_tail) > c->lds_max) ybuf_rows = 0;
-        if (total_bytes(ybuf_rows, with_tail) > c->lds_max)
-            return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the H update needs %zu bytes of LDS, the device has %zu", total_bytes(ybuf_rows, with_tail), c->lds_max);
-        tail.ybuf_rows = ybuf_rows;
-        h_bytes_mfma = total_bytes(ybuf_rows, with_tail);
-        if (with_tail) {
-            tail.gram_part = c->gramPartH; tail.stat_part = c->statPartH;
-            tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
+        const bool y_fits = c->nYrows > 0 && c->nYrows <= HT_YROWS_MAX;
+        const bool gm_ok = y_fits && !c->no_guided_mfma;
+        struct Form { bool gm; int yrows; bool tail; };
+        const Form forms[] = {{gm_ok, c->nYrows, with_tail}, {false, y_fits ? c->nYrows : 0, with_tail}, {false, 0, with_tail},
+                              {gm_ok, c->nYrows, false}, {false, y_fits ? c->nYrows : 0, false}, {false, 0, false}};
+        const Form* pick = nullptr;
+        for (const Form& f : forms) {
+            if (f.gm && !gm_ok) continue;
+            if (total_bytes(f.gm, f.yrows, f.tail) <= c->lds_max) { pick = &f; break; }
         }
+        if (!pick)
+            return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the H update needs %zu bytes of LDS, the device has %zu", total_bytes(false, 0, false), c->lds_max);
+        with_tail = pick->tail;
+        tail.ybuf_rows = pick->yrows;
+        tail.gm = pick->gm ? 1 : 0;
+        tail.nY = c->nYrows; tail.kg = kg; tail.rowtab = c->rowtab;
+        tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
+        h_bytes_mfma = total_bytes(pick->gm, pick->yrows, pick->tail);
+        if (with_tail) { tail.gram_part = c->gramPartH; tail.stat_part = c->statPartH; }
         if (c->loss_type == ALPINE_LOSS_KL) {
             DISPATCH_KT(c->KT, hipLaunchKernelGGL((h_update_mfma_kernel<KT_, 0>), dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
                                                    c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB, k_lo, k_hi, only_cov, tail));
@@ -1052,7 +1105,7 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
         }
     }
     HIPCHK(c, hipGetLastError());
-    c->tail_valid = with_tail && !c->h_update_valu;
+    c->tail_valid = with_tail && !(c->h_update_valu && !c->use_als && guided_total <= 64);
     return 0;
 }
 
@@ -1564,6 +1617,59 @@ extern "C" int alpine_eval_recon_direct(alpine_ctx* c, double* out)
     return sum_f64_partials(c, gx * gy, out);
 }
 
+// Diagnostics (tools/graph_vs_eager.py): the steady-state MU iteration as a hipGraph.  TWO iterations are captured (the W^TW and
+// B double buffers flip once per iteration, so the launch parameters repeat with period 2), without loss rows (their row
+// pointer advances every iteration) and without a communicator, and replayed n_pairs times.  Same kernels, same order, same
+// results as alpine_run(2 * n_pairs, 0); only the submission path differs.  Measured: no difference -- the stream is
+// never starved by the host (the kernel trace shows 0.3 us of gaps per iteration), so the production loop stays eager.
+extern "C" int alpine_debug_run_graph(alpine_ctx* c, int n_pairs)
+{
+    int rc = ready(c);
+    if (rc) return rc;
+    if (c->comm || c->use_als || c->transform_only || n_pairs < 1) return fail(c, ALPINE_ERR_UNSUPPORTED, "single-shard MU loop only");
+    const bool prof = c->prof;
+    c->prof = false;
+    c->loss_enabled = false;
+    for (int it = 0; it < 2; ++it) if ((rc = alpine_iter(c, 1))) return rc;          // reach the steady state (fused tails valid)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int it = 0; it < 2 && !rc; ++it) rc = alpine_iter(c, 1);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIPCHK(c, e);
+    HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int p = 0; p < n_pairs; ++p) HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    c->loss_enabled = true;
+    c->prof = prof;
+    c->pending_loss = true;
+    return 0;
+}
+
+// Diagnostics (tools/xcd_bias_sweep.py): re-divide the two sweeps with another even/odd bias ON THE SAME ctx, i.e. on the same
+// physical placement of X -- sweep times of two ctxs differ by +-2 % from placement alone, which hides an effect of this size.
+extern "C" int alpine_debug_set_xcd_bias(alpine_ctx* c, int per_mille)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int old = c->xcd_bias_pm;
+    c->xcd_bias_pm = std::max(-200, std::min(200, per_mille));
+    apply_sweep_geometry(c, c->sweep_bf);
+    auto need = [&](const SweepGeom& g) { return (int64_t)g.nwg * g.maxp * g.bf * c->KP; };
+    if (need(c->geomA) > c->piecesA_cap || need(c->geomB) > c->piecesB_cap) {
+        c->xcd_bias_pm = old;
+        apply_sweep_geometry(c, c->sweep_bf);
+        return fail(c, ALPINE_ERR_UNSUPPORTED, "the pieces buffers are too small for that division");
+    }
+    c->tail_valid = false;
+    return 0;
+}
+
 extern "C" int alpine_set_profiling(alpine_ctx* c, int enabled)
 {
     if (!c) return ALPINE_ERR_BAD_ARG;
@@ -1612,3 +1718,18 @@ extern "C" int alpine_read_buffer(alpine_ctx* c, int which, int64_t offset, int6
     HIPCHK(c, hipMemcpy(host, base + offset, sizeof(float) * n, hipMemcpyDeviceToHost));
     return 0;
 }
+
+#ifdef ALPINE_STAMPS
+extern "C" int alpine_debug_read_sweep_stamps(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(alpine::g_sweep_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int alpine_debug_read_sweep_hist(unsigned int* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(alpine::g_sweep_hist), sizeof(unsigned int) * n);
+}
+extern "C" int alpine_debug_read_hu_stamps(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(alpine::g_hu_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -25,11 +25,26 @@
 
 namespace alpine {
 
+// In-kernel time stamps (s_memrealtime, 10 ns ticks) for tools/: compiled only with -DALPINE_STAMPS (a throwaway build,
+// python alpine_amd/build.py --stamps -> libalpine_hip_stamps.so); the product library carries none.
+#ifdef ALPINE_STAMPS
+__device__ unsigned long long g_sweep_stamps[8 * 2048];     // per sweep workgroup: start, first stage, last stage done, end, flush ticks, segments, XCC id
+__device__ unsigned long long g_hu_stamps[16 * 8192];       // per H-update block: phase boundaries
+__device__ unsigned int g_sweep_hist[4 + 4096];             // [0] = launches so far; then per sweep launch: XCC id of workgroup 0 | workgroup 1 << 8 | grid << 16
+#define SG_STAMP_SET(i, v) do { if (threadIdx.x == 0) alpine::g_sweep_stamps[8 * (blockIdx.x & 2047) + (i)] = (v); } while (0)
+#define SG_NOW() __builtin_amdgcn_s_memrealtime()
+#define HU_STAMP(i) do { if (threadIdx.x == 0) alpine::g_hu_stamps[16 * (blockIdx.x & 8191) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SG_STAMP_SET(i, v) do {} while (0)
+#define SG_NOW() 0ull
+#define HU_STAMP(i) do {} while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MAX_COV = 16;       // covariates per model
-constexpr int MAX_COV_K = 64;     // guided components per covariate (and in total: they must sit in columns 0..63)
+constexpr int MAX_COV_K = 64;     // guided components PER covariate (the statistics kernels size their LDS for it); their sum may reach K
 
 struct CovMeta {
     int n_cov;
@@ -114,48 +129,109 @@ struct SweepGeom {
     int sub;      // consecutive spans per workgroup: a workgroup restarts its accumulators at every span boundary, so no
                   // float32 accumulator chain covers more than L <= SG_MAX_CHAIN contraction rows whatever the shard size
     int panel_fixed;  // timing-only ablation of the bf16 sweeps: every panel stage re-reads stage 0 (cache-resident) -> wrong results
+    int dL;       // rows moved from every span of an odd workgroup to every span of an even one (multiple of SG_ROW_ALIGN, 0 = equal
+                  // spans): workgroups are dispatched round-robin over the 8 XCDs and the XCDs do not stream this access pattern
+                  // at the same rate; the division is static, so results never depend on where a workgroup ran
 };
+
+// span v (= piece owner) belongs to workgroup v / sub; its length is L + dL (even workgroup) or L - dL (odd workgroup); the
+// spans of workgroups 2j and 2j + 1 together cover 2 * sub * L rows of the (tile, row) space
+__host__ __device__ inline int sg_span_len(const SweepGeom& g, int v) { return ((v / g.sub) & 1) ? g.L - g.dL : g.L + g.dL; }
+__host__ __device__ inline int64_t sg_span_start(const SweepGeom& g, int v)
+{
+    const int w = v / g.sub, s = v - w * g.sub;
+    return (int64_t)(w >> 1) * 2 * g.sub * g.L + (w & 1) * (int64_t)g.sub * (g.L + g.dL) + (int64_t)s * ((w & 1) ? g.L - g.dL : g.L + g.dL);
+}
+__host__ __device__ inline int sg_span_of_row(const SweepGeom& g, int64_t row)
+{
+    const int64_t pair_rows = 2 * (int64_t)g.sub * g.L, even_rows = (int64_t)g.sub * (g.L + g.dL);
+    const int64_t pb = row / pair_rows;
+    const int64_t rem = row - pb * pair_rows;
+    if (rem < even_rows) return (int)(2 * pb * g.sub + rem / (g.L + g.dL));
+    return (int)((2 * pb + 1) * g.sub + (rem - even_rows) / (g.L - g.dL));
+}
+
+inline int64_t sg_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int64_t sg_max64(int64_t a, int64_t b) { return a > b ? a : b; }
+inline int64_t sg_min64(int64_t a, int64_t b) { return a < b ? a : b; }
+// Stream-K geometry of a sweep (host side): a fixed grid of `slots` workgroups (as many as the
+// chip holds at once), each an equal share of the (tile,row) space.  forced > 0 asks for about `forced` workgroups per
+// tile instead (tests use it to exercise shares that do / do not cross tiles).  A workgroup's share is cut into `sub`
+// equal spans of L <= SG_MAX_CHAIN rows: it restarts its float32 accumulators at every span boundary and writes a piece
+// per span and tile, so the length of an accumulator chain -- and with it the rounding error of a sweep, which has the
+// same sign every iteration because X does not change -- is bounded independently of the shard size (the spans' pieces
+// are summed in float64 by the consumers).  cfg3's shares are 15 4xx-15 6xx rows: sub = 1, nothing changes there.
+inline SweepGeom sg_make_geom(int64_t F, int64_t R, int slots, int forced, int bf, int bias_pm)
+{
+    SweepGeom g{};
+    g.F = (int)F; g.R = (int)R; g.bf = bf;
+    g.nft = (int)((F + bf - 1) / bf);
+    const int64_t total = (int64_t)g.nft * R;
+    int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
+    want = sg_max64(1, sg_min64(want, total / SG_ROW_ALIGN));
+    const int64_t share = sg_round_up((total + want - 1) / want, SG_ROW_ALIGN);         // rows per workgroup
+    g.sub = (int)((share + SG_MAX_CHAIN - 1) / SG_MAX_CHAIN);
+    g.L = (int)sg_round_up((share + g.sub - 1) / g.sub, SG_ROW_ALIGN);
+    // uneven division between even and odd workgroups (SweepGeom::dL): as much of the asked bias as keeps the LONGER span
+    // within the accumulation cap (never at the price of more spans) and the shorter one above 3/4 of the mean
+    int64_t dL = (int64_t)g.L * bias_pm / 1000 / SG_ROW_ALIGN * SG_ROW_ALIGN;
+    const int64_t dmax = sg_min64((SG_MAX_CHAIN - g.L) / SG_ROW_ALIGN * SG_ROW_ALIGN, g.L / 4 / SG_ROW_ALIGN * SG_ROW_ALIGN);
+    dL = sg_max64(-dmax, sg_min64(dL, dmax));
+    g.dL = (int)dL;
+    int n_wg = (int)(total / ((int64_t)g.sub * g.L));                                   // first workgroup count whose shares cover `total`
+    while (sg_span_start(g, n_wg * g.sub) < total) ++n_wg;
+    while (n_wg > 1 && sg_span_start(g, (n_wg - 1) * g.sub) >= total) --n_wg;
+    g.nwg = n_wg * g.sub;
+    g.maxp = (int)((g.L + (dL < 0 ? -dL : dL) + R - 1) / R) + 1;
+    return g;
+}
 
 // A workgroup's walk over its `sub` consecutive spans, cut at tile boundaries into segments (tile ft, rows [r_begin, r_end)
 // of that tile); every segment owns one piece: slot = span * maxp + (ft - first tile of the span).  All wave-uniform.
 struct SgWalk {
     int64_t pos, pos_end, span_end;
-    int span, first_tile;
+    int span, first_tile, len;
 };
-__device__ __forceinline__ void sg_walk_init(SgWalk& s, const SweepGeom& g, int wg)
+__host__ __device__ __forceinline__ void sg_walk_init(SgWalk& s, const SweepGeom& g, int wg)
 {
     const int64_t total = (int64_t)g.nft * g.R;
     s.span = wg * g.sub;
-    s.pos = (int64_t)s.span * g.L;
-    s.pos_end = min(total, s.pos + (int64_t)g.sub * g.L);
-    s.span_end = min(s.pos_end, s.pos + g.L);
+    s.len = sg_span_len(g, s.span);
+    s.pos = sg_span_start(g, s.span);
+    s.pos_end = s.pos + (int64_t)g.sub * s.len;
+    if (s.pos_end > total) s.pos_end = total;
+    s.span_end = s.pos + s.len;
+    if (s.span_end > s.pos_end) s.span_end = s.pos_end;
     s.first_tile = (int)(s.pos / g.R);
 }
-__device__ __forceinline__ bool sg_walk_next(SgWalk& s, const SweepGeom& g, int& ft, int& r_begin, int& r_end, int64_t& slot)
+__host__ __device__ __forceinline__ bool sg_walk_next(SgWalk& s, const SweepGeom& g, int& ft, int& r_begin, int& r_end, int64_t& slot)
 {
     if (s.pos >= s.pos_end) return false;
     if (s.pos == s.span_end) {                   // next span of this workgroup: fresh accumulators, fresh pieces
         ++s.span;
-        s.span_end = min(s.pos_end, s.span_end + g.L);
+        s.span_end += s.len;
+        if (s.span_end > s.pos_end) s.span_end = s.pos_end;
         s.first_tile = (int)(s.pos / g.R);
     }
     ft = (int)(s.pos / g.R);
     r_begin = (int)(s.pos - (int64_t)ft * g.R);
-    r_end = (int)min((int64_t)g.R, r_begin + (s.span_end - s.pos));
+    const int64_t r_stop = r_begin + (s.span_end - s.pos);
+    r_end = (int)(r_stop < (int64_t)g.R ? r_stop : (int64_t)g.R);
     s.pos += r_end - r_begin;
     slot = (int64_t)s.span * g.maxp + (ft - s.first_tile);
     return true;
 }
 
 // pieces that contribute to tile ft: workgroups w_lo..w_hi; piece index of w for this tile
-__device__ __forceinline__ void sg_tile_pieces(const SweepGeom& g, int ft, int& w_lo, int& w_hi)
+__host__ __device__ __forceinline__ void sg_tile_pieces(const SweepGeom& g, int ft, int& w_lo, int& w_hi)
 {
-    w_lo = (int)(((int64_t)ft * g.R) / g.L);
-    w_hi = min(g.nwg - 1, (int)((((int64_t)ft + 1) * g.R - 1) / g.L));
+    w_lo = sg_span_of_row(g, (int64_t)ft * g.R);
+    w_hi = sg_span_of_row(g, ((int64_t)ft + 1) * g.R - 1);
+    if (w_hi > g.nwg - 1) w_hi = g.nwg - 1;
 }
-__device__ __forceinline__ int64_t sg_piece_offset(const SweepGeom& g, int w, int ft, int KP)
+__host__ __device__ __forceinline__ int64_t sg_piece_offset(const SweepGeom& g, int w, int ft, int KP)
 {
-    const int first = (int)(((int64_t)w * g.L) / g.R);
+    const int first = (int)(sg_span_start(g, w) / g.R);
     return ((int64_t)w * g.maxp + (ft - first)) * g.bf * KP;
 }
 
@@ -331,7 +407,7 @@ void stream_gemm_kernel(const float* __restrict__ S, const float* __restrict__ P
 
 // Offset of the piece that workgroup w wrote for tile ft, for w_lo < w <= w_hi (w_lo = first workgroup that touches ft):
 // such a workgroup's span STARTS inside ft, so ft is its piece 0 -- no division needed.
-__device__ __forceinline__ int64_t sg_piece_offset_inner(const SweepGeom& g, int w, int KP)
+__host__ __device__ __forceinline__ int64_t sg_piece_offset_inner(const SweepGeom& g, int w, int KP)
 {
     return (int64_t)w * g.maxp * g.bf * KP;
 }
@@ -373,6 +449,13 @@ __global__ __launch_bounds__(256)
 void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ out, int rows, int KP, SweepGeom g)
 {
     reduce_pieces_block(pieces, out, rows, KP, g, blockIdx.x, gridDim.x);
+}
+
+// Placement report of a sweep launch (alpine_finalize_X's probe, see SweepGeom::dL): workgroup 0 writes the XCC id it runs on.
+__device__ __forceinline__ void sg_report_xcc(int* __restrict__ xcc_out)
+{
+    if (xcc_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        *xcc_out = (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u);        // HW_REG_XCC_ID
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1243,12 +1326,52 @@ __device__ __forceinline__ void hstats_tail(const float* __restrict__ trall, int
     }
 }
 
+// stacked row r of Y: first column / columns of its covariate, offset of B_i[r - yoff_i][0] in the packed B, lam (Fro: 2 lam)
+struct GuidedRow { int off, k, base; float lam; };
+
 struct HTail {
     float* gram_part;       // [gridDim.x][KP*KP], nullptr = no tail
     float* stat_part;       // [groups][nstat]
     int nstat, max_k, max_ct;
     int ybuf_rows;          // rows of Y the block copies into LDS (all of them when they fit HT_YROWS_MAX, else 0 = read Y from global)
+    int gm;                 // 1: guided terms as two small matrix products on the MFMA (below); needs 0 < nY <= 32 and the Y copy in LDS
+    int nY, kg;             // gm: rows of Y in total; guided columns rounded up to a multiple of 8
+    const struct GuidedRow* rowtab;   // gm: [32] device table, stacked row of Y -> its covariate's columns / B rows / lam
 };
+
+// Guided terms of the H update as two small matrix products (gm path).  With every covariate's B_i stacked into ONE
+// block-structured matrix Ball[r][k] (r = row of the stacked Y: covariate i's classes are rows yoff_i .., k = column of H:
+// covariate i's components are columns off_i ..; zero elsewhere) main.py:636-650 reads
+//     bh  = Ball H              (all classes of all covariates at once: [nY] x cells)
+//     KL : num += (lam Ball)^T (Y / max(bh, eps)),  den += (lam Ball)^T 1        Fro: num += (2 lam Ball)^T Y,  den += (2 lam Ball)^T bh
+// and the block structure makes "covariate i's terms touch only covariate i's columns" automatic (also for the block-coordinate
+// branch, which updates one covariate's columns at a time).  Both products run on v_mfma_f32_32x32x2_f32 with the register
+// trick of the 2 W^TW H product: the contraction index is visited in the order a lane holds it (C/D layout), so H (for bh) and
+// z = Y / bh (for the numerator) are B operands straight from the registers they are in; the A operands are gathered from the
+// block's LDS copy of the packed B through a 32-entry row table (no stacked copy is materialised).  12 + 4 MFMAs at cfg3 instead
+// of a dependent scalar chain with a cross-lane exchange per (covariate, class): 7.7 -> 3.x us of a 32 us block (in-kernel stamps).
+
+// bh[r][cell] = sum_k Ball[r][k] H[cell][k] over the guided columns, H in C/D registers (lane (c, h): cell c, k = 32m + 8q + 4h + e);
+// result in C/D layout: lane (c, h) holds rows r = 8q' + 4h + e' of cell c.  A operand of lane (c, h): Ball[r = c][k].
+template <int KT, int GT>
+__device__ __forceinline__ void guided_bh(const float* __restrict__ Bl, const GuidedRow& mine, int kg, const f32x4 (&hreg)[KT][4], int h, f32x16& bh)
+{
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bh[e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < GT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (32 * m + 8 * q >= kg) continue;                                     // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 32 * m + 8 * q + 4 * h + e - mine.off;
+                const bool in = (unsigned)kk < (unsigned)mine.k;
+                const float a = Bl[mine.base + (in ? kk : 0)];
+                bh = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? a : 0.f, hreg[m][q][e], bh, 0, 0, 0);
+            }
+        }
+}
 
 // LOSS: 0 = KL, 1 = Frobenius guided terms (a template parameter: as a run-time select every element of the guided loops
 // computed both forms and picked one).
@@ -1262,7 +1385,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     // [k_lo, k_hi) of one component group are updated; guided terms only for that group's covariate (only_cov),
     // none for the unguided group (only_cov = n_cov).
     constexpr int KP = 32 * KT, LD = KP + 4, TRSZ = 32 * LD;
-    constexpr int GT = KT < 2 ? KT : 2;            // k tiles that can hold guided columns (sum k_i <= 64)
+    constexpr int GT = KT;                         // k tiles that can hold guided columns: all of them (sum k_i up to K)
     extern __shared__ float smem[];
     float* M2l = smem;                             // [k'][k] = 2 * WtW
     float* Bl = smem + KP * KP;
@@ -1272,40 +1395,50 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     float* trall = smem + KP * KP + ((nB + 3) & ~3);                 // 4 x [32][KP + 4]: the waves' tiles of one 128-cell group
     float* tr = trall + wave * TRSZ;
     float* ybuf = trall + 4 * TRSZ;                                                 // [ybuf_rows][128]: Y of the block's cells
-    unsigned char* hs_smem = reinterpret_cast<unsigned char*>(ybuf + tail.ybuf_rows * HS_CELLS);   // tail only: statistics scratch
+    const bool gm = tail.gm != 0;                                                   // kernel-uniform
+    const int ybuf_alloc = gm ? (tail.ybuf_rows + 7) / 8 * 8 : tail.ybuf_rows;      // gm: padded with zero rows to a multiple of 8
+    GuidedRow* rowtab = reinterpret_cast<GuidedRow*>(ybuf + ybuf_alloc * HS_CELLS);  // gm: [32] stacked rows of Y -> their covariate
+    unsigned char* hs_smem = reinterpret_cast<unsigned char*>(rowtab + (gm ? 32 : 0));   // tail only: statistics scratch
     const bool with_tail = tail.gram_part != nullptr;
     const bool y_lds = tail.ybuf_rows > 0;
+    HU_STAMP(0);
     {
         // Y of this block's 128 cells: one load phase up front instead of a dependent global load per (covariate, class)
         const int64_t cell0 = (int64_t)blockIdx.x * HS_CELLS;
-        for (int idx = tid; idx < tail.ybuf_rows * HS_CELLS; idx += 256) {
+        for (int idx = tid; idx < ybuf_alloc * HS_CELLS; idx += 256) {
             const int row = idx >> 7, t = idx & (HS_CELLS - 1);
-            ybuf[idx] = cell0 + t < N ? Y[(int64_t)row * Np + cell0 + t] : 0.f;
+            ybuf[idx] = (row < tail.ybuf_rows && cell0 + t < N) ? Y[(int64_t)row * Np + cell0 + t] : 0.f;
         }
     }
     for (int idx = tid; idx < KP * KP / 4; idx += 256)
         reinterpret_cast<f32x4*>(M2l)[idx] = 2.f * reinterpret_cast<const f32x4*>(WtW)[idx];
     for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];
+    if (gm && tid < 32) rowtab[tid] = tail.rowtab[tid];                        // built once on the host (launch_h_update)
     __syncthreads();
+    HU_STAMP(1);
 
     {
         const int64_t grp = blockIdx.x;                                        // 128-cell group
         const int64_t n0 = (grp * 4 + wave) * 32;
-        if (n0 < N) {                                                          // wave-uniform
+        const bool active = n0 < N;                                            // wave-uniform
+        f32x4 hreg[KT][4];
+        bool valid = false;
+        if (active) {
             const int64_t n = n0 + c;
-            const bool valid = n < N;
+            valid = n < N;
             const int ft = (int)(n0 / g.bf), fl0 = (int)(n0 % g.bf);
             int w_lo, w_hi;
             sg_tile_pieces(g, ft, w_lo, w_hi);
 
             // whole-row global accesses, C/D layout in registers (rows n0 .. n0+31 exist: H and the pieces are padded to 128 rows)
-            f32x4 hreg[KT][4], xreg[KT][4];
+            f32x4 xreg[KT][4];
             {
                 f32x4 hraw[(32 * KT * 8) / 64];
                 tile_load_issue<KT>(H + n0 * KP, lane, hraw);          // in flight behind the pieces' loads
                 sg_sum_pieces_rows<KT>(pieces, g, ft, fl0, w_lo, w_hi, tr, lane, xreg);
                 tile_raw_to_cd<KT>(hraw, tr, lane, hreg);
             }
+            HU_STAMP(2);
 
             f32x16 acc[KT];
 #pragma unroll
@@ -1323,6 +1456,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                         for (int mo = 0; mo < KT; ++mo)
                             acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], hreg[m][q][e], acc[mo], 0, 0, 0);
                     }
+            HU_STAMP(3);
 
             // numerator = 2 W^TX (+ guided), denominator = (2 W^TW) H (+ guided): accumulated IN PLACE in xreg / acc so that the
             // kernel's live state stays at three tiles (H, numerator, denominator) -> 2 waves per SIMD
@@ -1330,6 +1464,49 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
             for (int m = 0; m < KT; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xreg[m][q] = 2.f * xreg[m][q];
+            if (gm) {
+                // guided terms as two small products on the MFMA (see GuidedRow)
+                f32x16 bh;
+                guided_bh<KT, GT>(Bl, rowtab[c], tail.kg, hreg, h, bh);
+                f32x16 zz;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                    for (int ee = 0; ee < 4; ++ee) {
+                        if (8 * qq >= tail.nY) { zz[4 * qq + ee] = 0.f; continue; }              // wave-uniform
+                        const float y = ybuf[(8 * qq + 4 * h + ee) * HS_CELLS + wave * 32 + c];
+                        zz[4 * qq + ee] = (LOSS == 0) ? y / fmaxf(bh[4 * qq + ee], eps) : y;
+                    }
+#pragma unroll
+                for (int m = 0; m < GT; ++m) {
+                    if (32 * m >= tail.kg) continue;                                              // wave-uniform
+                    f32x16 nacc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) nacc[4 * q + e] = xreg[m][q][e];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        if (8 * qq >= tail.nY) continue;                                          // wave-uniform
+#pragma unroll
+                        for (int ee = 0; ee < 4; ++ee) {
+                            // A operand of lane (c, h): (lam B)[r][k] with r = 8q' + 4h + e', k = 32m + c
+                            const GuidedRow gr = rowtab[8 * qq + 4 * h + ee];
+                            const int kk = 32 * m + c - gr.off;
+                            const bool in = (unsigned)kk < (unsigned)gr.k;
+                            const float bv = Bl[gr.base + (in ? kk : 0)];
+                            const float a2 = in ? gr.lam * bv : 0.f;
+                            nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, zz[4 * qq + ee], nacc, 0, 0, 0);
+                            // KL: den += sum_r lam B[r][k] (a product with ones); Fro: den += sum_r 2 lam B[r][k] bh[r]
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, (LOSS == 0) ? 1.f : bh[4 * qq + ee], acc[m], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xreg[m][q][e] = nacc[4 * q + e];
+                }
+            } else {
             // A covariate's k_i components live in [off, off + k_i): of the 8 groups of 8 components that a lane pair (h = 0, 1)
             // holds in a k tile only those that overlap the range are touched (wave-uniform branches on scalars) -- with
             // k_i = 5 that is one group of 8 instead of all 64 components, per covariate and class (in-kernel stamps: the
@@ -1372,6 +1549,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                         }
                 }
             }
+            }
 
 #pragma unroll
             for (int m = 0; m < KT; ++m)
@@ -1387,6 +1565,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                     }
                 }
             (void)K;
+            HU_STAMP(4);
             // leaves the updated tile row-major in tr (the tail reads it there)
             tile_store_cd<KT>(H + n0 * KP, tr, lane, hreg, (int)min((int64_t)32, (int64_t)N - n0));
         } else if (with_tail) {
@@ -1394,8 +1573,10 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
         }
         if (!with_tail) return;                                                // kernel-uniform
 
+        HU_STAMP(5);
         __syncthreads();                                                       // the four tiles of this group are in LDS
         gram_of_lds_tiles<KT>(trall, wave, lane, tail.gram_part + (int64_t)blockIdx.x * KP * KP);      // H H^T over the block's 128 cells
+        HU_STAMP(6);
         if (meta.n_cov > 0) {
             if (y_lds) {
                 hstats_tail(trall, LD, TRSZ, ybuf, Bl, meta, tail.stat_part + grp * tail.nstat, grp * HS_CELLS, N, eps, tail.max_k, tail.max_ct, hs_smem);
@@ -1408,6 +1589,7 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
                              hs_smem, tid >> 7, grp);
             }
         }
+        HU_STAMP(7);
     }
 }
 

@@ -230,8 +230,9 @@ __device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RIN
 template <int KT, int NPX, int NPP, int NW>
 __global__ __launch_bounds__(64 * NW, (KT <= 2 && NW == 4 ? 2 : 1))
 void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_plane, const unsigned short* __restrict__ P,
-                             int64_t p_plane, const float* __restrict__ Pf, float* __restrict__ pieces, SweepGeom g)
+                             int64_t p_plane, const float* __restrict__ Pf, float* __restrict__ pieces, SweepGeom g, int* __restrict__ xcc_out)
 {
+    sg_report_xcc(xcc_out);
     // Panel source: NPP == 1 reads the rounded bf16 k-packed copy P (made by pack_bf16_kernel once per sweep);
     // NPP == 3 reads the float32 master Pf[R][KP] directly and splits it into its three exact bf16 planes while
     // staging it into LDS (4 instead of 6 bytes per panel element through the fabric, and no pack pass: every

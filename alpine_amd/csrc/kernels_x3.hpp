@@ -145,8 +145,9 @@ __device__ __forceinline__ void x3_stage(f32x16 (&acc)[KT][4 * NH], f32x4 (&x)[X
 template <int KT, int NH, int ABL = 0>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
-                           int64_t ldS, SweepGeom g)
+                           int64_t ldS, SweepGeom g, int* __restrict__ xcc_out)
 {
+    sg_report_xcc(xcc_out);
     static_assert(KT * NH <= 4, "256 accumulator registers per lane");
     constexpr int KP = 32 * KT;
     constexpr int WAVE_F = 128 * NH, BLOCK_F = 4 * WAVE_F;
@@ -164,6 +165,9 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
     const int c = lane & 31, h = lane >> 5;
     SgWalk walk;
     sg_walk_init(walk, g, blockIdx.x);
+    SG_STAMP_SET(0, SG_NOW());
+    unsigned long long st_flush = 0, st_first = 0, st_segs = 0;       // stamps build only
+    (void)st_flush; (void)st_first; (void)st_segs;
 
     float pf[PVS][8];
     f32x4 x[X3_RING][NH][8];
@@ -250,6 +254,7 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
                     x[p][hf][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((hf == 0 ? xrow0 : xrow1) + (int64_t)(16 * p + e) * ldS));
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (st_first == 0) st_first = SG_NOW();
 
         int t = 0;
         for (; t + 2 < nst; ++t) {
@@ -270,6 +275,8 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
         float* out = pieces + (slot * BLOCK_F + wave * WAVE_F) * KP;
+        const unsigned long long st_f0 = SG_NOW();
+        SG_STAMP_SET(2, st_f0);
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
             if ((hf == 1 && f1 == f0) || g.panel_fixed == 2) break;    // second half outside F: nothing to write (panel_fixed == 2: timing-only ablation of the flush)
@@ -281,7 +288,22 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
                 sg_flush_tile<KT>(flush_tr[wave], d, out + (int64_t)(128 * hf + tt) * KP, 4 * KP, lane);
             }
         }
+        st_flush += SG_NOW() - st_f0;
+        ++st_segs;
     }
+    SG_STAMP_SET(1, st_first);
+    SG_STAMP_SET(3, SG_NOW());
+    SG_STAMP_SET(4, st_flush);
+    SG_STAMP_SET(5, st_segs);
+#ifdef ALPINE_STAMPS
+    {
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); SG_STAMP_SET(6, (unsigned long long)(xcc & 15u));
+        // launch history: workgroup 0 claims the launch's slot, workgroup 1 adds its XCC id to the same slot (it reads the launch
+        // count before workgroup 0 of the NEXT launch can bump it: launches on one stream do not overlap)
+        if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned n = atomicAdd(&alpine::g_sweep_hist[0], 1u); atomicOr(&alpine::g_sweep_hist[4 + (n & 4095)], (xcc & 15u) | (gridDim.x << 16)); }
+        if (threadIdx.x == 0 && blockIdx.x == 1) alpine::g_sweep_hist[2] = xcc & 15u;
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -332,8 +354,9 @@ __device__ __forceinline__ void sg_flush_tile16(float* __restrict__ tr, const f3
 template <int KT, int NH, int M16A = 2 * KT>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
-                            int64_t ldS, SweepGeom g)
+                            int64_t ldS, SweepGeom g, int* __restrict__ xcc_out)
 {
+    sg_report_xcc(xcc_out);
     static_assert(KT * NH <= 4, "256 accumulator registers per lane");
     static_assert(M16A == 2 * KT || M16A == 2 * KT - 1, "at most one padding tile");
     constexpr int KP = 32 * KT, M16 = 2 * KT;

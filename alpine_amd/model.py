@@ -306,19 +306,16 @@ class ALPINE:
     # limits of libalpine_hip.so that the reference does not have ("Deviations"): checked here so that the
     # user gets a Python-side message before any device work, instead of a late native status
     MAX_TOTAL_COMPONENTS = 128
-    MAX_GUIDED_COMPONENTS = 64
+    MAX_COVARIATE_COMPONENTS = 64           # per covariate; their sum may reach the total
     MAX_COVARIATES = 16
 
     def _check_supported(self, n_sample: int) -> None:
         ks = list(self.n_covariate_components)
-        if any(k == 0 for k in ks):
-            raise NotImplementedError("n_covariate_components entries of 0 (a covariate without guided components; the reference "
-                                      "accepts them, main.py:335) are not supported by the MI355X build: drop that covariate instead")
         if len(ks) > self.MAX_COVARIATES:
             raise NotImplementedError(f"more than {self.MAX_COVARIATES} covariates are not supported by the MI355X build (got {len(ks)})")
-        if sum(ks) > self.MAX_GUIDED_COMPONENTS:
-            raise NotImplementedError(f"sum(n_covariate_components) = {sum(ks)} > {self.MAX_GUIDED_COMPONENTS}: the guided components "
-                                      "must fit in the first 64 columns of W / H in the MI355X build")
+        if any(k > self.MAX_COVARIATE_COMPONENTS for k in ks):
+            raise NotImplementedError(f"more than {self.MAX_COVARIATE_COMPONENTS} guided components for ONE covariate are not supported by the "
+                                      f"MI355X build (got {max(ks)}; their sum over the covariates may reach the total)")
         if self.total_components > self.MAX_TOTAL_COMPONENTS:
             raise NotImplementedError(f"n_components + sum(n_covariate_components) = {self.total_components} > "
                                       f"{self.MAX_TOTAL_COMPONENTS} is not supported by the MI355X build")

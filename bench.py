@@ -55,6 +55,8 @@ WORKLOADS = {
     "cfg3": dict(genes=20000, cells=200000, ku=50, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
     "cfg4": dict(genes=20000, cells=1000000, ku=100, kcov=[5], alpha_W=0.0, orth_W=0.0, l1_ratio_W=0.0),
     "tiny": dict(genes=2000, cells=5000, ku=20, kcov=[2], alpha_W=0.0, orth_W=0.0, l1_ratio_W=0.0),
+    # cfg3's matrix with K = 22 + [5, 5] = 32 (one MFMA tile of components): the shape at which the x3 kernels fit two waves per SIMD
+    "cfg3_k32": dict(genes=20000, cells=200000, ku=22, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
 }
 
 

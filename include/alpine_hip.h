@@ -121,6 +121,8 @@ typedef struct {
     int32_t reserved;
     int32_t span_rows_a, span_rows_b;                      /* contraction rows one float32 accumulator chain covers (<= ALPINE_MAX_ACCUMULATION_ROWS) */
     int32_t spans_per_workgroup_a, spans_per_workgroup_b;  /* accumulator restarts + 1 of a sweep workgroup (1 at BASELINE config 3) */
+    int32_t xcd_bias_per_mille;     /* spans of even sweep workgroups are this much longer (negative: shorter) than the mean, odd ones the opposite */
+    int32_t xcc_of_workgroup0;      /* placement probe: XCC id workgroup 0 of a one-per-CU grid landed on (-1: not probed) */
 } alpine_info;
 
 /* Number of floats in the per-iteration reduce block for a configuration (so a caller can allocate
@@ -243,6 +245,10 @@ enum { ALPINE_KERNEL_SWEEP_XHT = 0, ALPINE_KERNEL_SWEEP_WTX = 1, ALPINE_KERNEL_A
 /* enabled: 0 = off, 1 = every launch, n > 1 = the launches of every n-th iteration only (an event record between two kernels
  * costs the stream about 2 us, which matters for sub-millisecond iterations). */
 int alpine_set_profiling(alpine_ctx* ctx, int enabled);
+/* Diagnostics: span length of even sweep workgroups +per_mille, odd -per_mille (same results up to summation order). */
+int alpine_debug_set_xcd_bias(alpine_ctx* ctx, int per_mille);
+/* Diagnostics: 2 * n_pairs steady-state MU iterations (no loss rows, no communicator) replayed from a hipGraph of two. */
+int alpine_debug_run_graph(alpine_ctx* ctx, int n_pairs);
 int alpine_get_kernel_time(alpine_ctx* ctx, int which, double* total_ms, int64_t* launches);
 
 /* Debug/test access to device-resident intermediates (synchronises): copies n floats starting at

@@ -172,6 +172,25 @@ CASES = [
          covariates=[("cond", ["a", "b", "c"], 0.0)],
          params=dict(n_components=5, n_covariate_components=[3], lam=[50.0], eps=1e-4, random_state=7,
                      orth_W=0.2, alpha_W=0.1, l1_ratio_W=1.0)),
+    # round 3: model sizes the reference accepts and the build used to refuse (main.py:331-336 rejects only n < 0)
+    # a covariate WITHOUT guided components (k_i = 0): it contributes only its prediction-loss column
+    dict(name="k0_split", transform_iters=8, n_cells=140, n_genes=70, seed=31, T=20,
+         covariates=[("c1", ["x", "y", "z"], 0.08), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=5, n_covariate_components=[0, 3], lam=[1e3, 5e2])),
+    dict(name="k0_fro", n_cells=120, n_genes=64, seed=32, T=15,
+         covariates=[("c1", ["x", "y"], 0.0), ("c2", ["p", "q", "r"], 0.05)],
+         params=dict(n_components=4, n_covariate_components=[2, 0], lam=[5.0, 2.0],
+                     loss_type="frobenius", orth_W=0.05, alpha_W=0.2, l1_ratio_W=0.5)),
+    # more than 64 guided components in total (40 + 30 of K = 90): guided columns in every 32-column tile of H
+    dict(name="guided_wide", transform_iters=6, n_cells=200, n_genes=100, seed=33, T=8,
+         covariates=[("c1", ["x", "y", "z"], 0.0), ("c2", ["p", "q"], 0.02)],
+         params=dict(n_components=20, n_covariate_components=[40, 30], lam=[1e3, 2e2], orth_W=0.05, alpha_W=0.3, l1_ratio_W=0.5)),
+    dict(name="guided_wide_fro", n_cells=160, n_genes=96, seed=34, T=8,
+         covariates=[("c1", ["x", "y", "z", "w"], 0.0), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=24, n_covariate_components=[36, 36], lam=[4.0, 2.0], loss_type="frobenius")),
+    dict(name="als_guided_wide", n_cells=150, n_genes=90, seed=35, T=5,
+         covariates=[("c1", ["x", "y", "z"], 0.0), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=10, n_covariate_components=[40, 30], lam=[1e3, 5e2], use_als=True, orth_W=0.05)),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,

@@ -9,29 +9,14 @@
 #include <algorithm>
 using namespace alpine;
 
-static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced)     // same as alpine_hip.hip
-{
-    SweepGeom g{};
-    g.F = (int)F; g.R = (int)R;
-    g.bf = SG_BLOCK_F;
-    g.nft = (int)((F + SG_BLOCK_F - 1) / SG_BLOCK_F);
-    const int64_t total = (int64_t)g.nft * R;
-    int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;
-    want = std::max<int64_t>(1, std::min<int64_t>(want, total / SG_ROW_ALIGN));
-    g.sub = 1;                                 // one span per workgroup here (the library caps spans at SG_MAX_CHAIN rows)
-    g.L = (int)round_up((total + want - 1) / want, SG_ROW_ALIGN);
-    g.nwg = (int)((total + g.L - 1) / g.L);
-    g.maxp = (int)((g.L + R - 1) / R) + 1;
-    return g;
-}
+static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced) { return sg_make_geom(F, R, slots, forced, SG_BLOCK_F, 0); }   // the library's own division
 
 template <int KT, int RING, int PASSES>
 static void run(const char* name, const float* S, const float* P, float* slab, int64_t ldS, int F, int R, int split, int reps,
                 unsigned long long* clk)
 {
     const SweepGeom g = make_geom(F, R, 512, split);
-    const int grid = g.nwg;
+    const int grid = (g.nwg + g.sub - 1) / g.sub;
     const int rps = g.L;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> ms(reps);
