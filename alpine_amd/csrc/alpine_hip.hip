@@ -116,6 +116,7 @@ struct alpine_ctx {
     int comm_ranks = 1, comm_rank = 0;
     bool transform_only = false;
     bool use_als = false;
+    bool tail_stats_per_cov = false;  // env ALPINE_HIP_TAIL_STATS=per_covariate: the fused tail's statistics one covariate at a time (A/B)
     bool no_guided_mfma = false;      // env ALPINE_HIP_GUIDED=scalar: the per-(covariate, class) scalar form of the guided terms instead of the MFMA products (A/B)
     GuidedRow* rowtab = nullptr;      // [32] stacked rows of Y -> covariate (guided terms on the MFMA, see GuidedRow)
     bool xcd_bias_auto = true;        // no ALPINE_HIP_XCD_BIAS in the environment: decided by the placement probe (create_impl)
@@ -304,6 +305,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->ablate_flush = getenv_is("ALPINE_HIP_ABLATE_FLUSH", '1');
     if (const char* e = std::getenv("ALPINE_HIP_X3_ABLATE")) c->x3_ablate = std::atoi(e);
 #endif
+    c->tail_stats_per_cov = getenv_is("ALPINE_HIP_TAIL_STATS", 'p');
     if (const char* e = std::getenv("ALPINE_HIP_GUIDED")) c->no_guided_mfma = (std::strcmp(e, "scalar") == 0);
     if (const char* e = std::getenv("ALPINE_HIP_XCD_BIAS")) { c->xcd_bias_pm = std::max(-200, std::min(200, std::atoi(e))); c->xcd_bias_auto = false; }
     if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
@@ -1067,6 +1069,7 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
         int guided = 0;
         for (int i = 0; i < c->n_cov; ++i) guided += c->cov_k[i];
         const int kg = (guided + 7) / 8 * 8;
+        const bool merged_ok = guided + c->nYrows <= HT_MERGED_ROWS && !c->tail_stats_per_cov;
         // LDS on top of the update's own, in order of preference (same results in every form, fewer launches / less latency first):
         //   gm  = guided terms as two small matrix products on the MFMA: needs all of Y's rows in LDS (<= 32)
         //   y   = the Y copy of the block's cells in LDS (else Y is read from global memory per covariate and class)
@@ -1074,7 +1077,8 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
         auto total_bytes = [&](bool gm, int ybuf_rows, bool tail_on) {
             size_t b = base + sizeof(float) * (size_t)(gm ? (ybuf_rows + 7) / 8 * 8 : ybuf_rows) * HS_CELLS;
             if (gm) b += sizeof(GuidedRow) * 32;
-            if (tail_on) b += ybuf_rows ? hstats_tail_bytes(max_k, max_ct) : 2 * hstats_group_bytes(max_k, max_ct);
+            if (tail_on) b += ybuf_rows ? (merged_ok ? hstats_merged_bytes(guided, c->nYrows) : hstats_tail_bytes(max_k, max_ct))
+                                        : 2 * hstats_group_bytes(max_k, max_ct);
             return b;
         };
         const bool y_fits = c->nYrows > 0 && c->nYrows <= HT_YROWS_MAX;
@@ -1093,6 +1097,7 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
         tail.ybuf_rows = pick->yrows;
         tail.gm = pick->gm ? 1 : 0;
         tail.nY = c->nYrows; tail.kg = kg; tail.rowtab = c->rowtab;
+        tail.merged = (merged_ok && pick->yrows > 0) ? 1 : 0; tail.guided = guided;
         tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
         h_bytes_mfma = total_bytes(pick->gm, pick->yrows, pick->tail);
         if (with_tail) { tail.gram_part = c->gramPartH; tail.stat_part = c->statPartH; }

@@ -1326,6 +1326,85 @@ __device__ __forceinline__ void hstats_tail(const float* __restrict__ trall, int
     }
 }
 
+// The same statistics for ALL covariates in one pass (two block barriers in all instead of two or three per covariate): used
+// when the guided components and label levels of all covariates together fit HT_MERGED_ROWS rows of 128 floats of scratch.
+// Same per-(class, component) arithmetic and summation order as hstats_tail -> bitwise the same statistics.
+//   smem: double lred[MAX_COV][2]; float hbuf[sum k_i][128]; float zbuf[sum C_i][128]
+constexpr int HT_MERGED_ROWS = 32;
+__host__ __device__ inline size_t hstats_merged_bytes(int guided, int nY)
+{
+    return (sizeof(double) * MAX_COV * 2 + sizeof(float) * (size_t)(guided + nY) * HS_CELLS + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ void hstats_tail_merged(const float* __restrict__ trall, int LD, int TRSZ, const float* __restrict__ ybuf,
+                                                   const float* __restrict__ Bl, const CovMeta& meta, float* __restrict__ out,
+                                                   int64_t cell0, int N, float eps, int guided, unsigned char* __restrict__ smem)
+{
+    double* lred = reinterpret_cast<double*>(smem);                                     // [MAX_COV][2]
+    float (*hbuf)[HS_CELLS] = reinterpret_cast<float (*)[HS_CELLS]>(lred + MAX_COV * 2);   // [sum k_i][128], row off_i + k
+    float (*zbuf)[HS_CELLS] = hbuf + guided;                                            // [sum C_i][128], row yoff_i + c
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool cellthread = tid < HS_CELLS;
+    const bool valid = cellthread && cell0 + tid < N;
+    const float* hrow = trall + (tid >> 5 & 3) * TRSZ + (tid & 31) * LD;
+    if (cellthread) {
+        for (int i = 0; i < meta.n_cov; ++i) {
+            const int ki = meta.k[i], Ci = meta.lev[i], off = meta.off[i], bo = meta.boff[i], yo = meta.yoff[i];
+            const float lam = meta.lam[i];
+            for (int k = 0; k < ki; ++k) hbuf[off + k][tid] = valid ? hrow[off + k] : 0.f;
+            double lacc = 0.0;
+            for (int c = 0; c < Ci; ++c) {
+                float bh = 0.f;
+                for (int k = 0; k < ki; ++k) bh = fmaf(Bl[bo + c * ki + k], hbuf[off + k][tid], bh);
+                const float y = valid ? ybuf[(yo + c) * HS_CELLS + tid] : 0.f;
+                float z;
+                if (meta.loss_type == 0) {
+                    const float yh = fmaxf(bh, eps);
+                    z = lam * (y / yh);
+                    if (valid) lacc += (double)(y * logf(fmaxf(y / yh, eps)) - y + yh);
+                } else {
+                    z = y;
+                    const float d = y - bh;
+                    if (valid) lacc += (double)(d * d);
+                }
+                zbuf[yo + c][tid] = valid ? z : 0.f;
+            }
+            const double ws = wave_sum_f64_dpp(lacc);                  // waves 0 and 1 hold the block's 128 cells
+            if (lane == 0) lred[2 * i + wave] = ws;
+        }
+    }
+    __syncthreads();
+    // every (covariate, class, component) product and every (covariate, component) sum is one wave-wide reduction over the 128
+    // cells; the four waves take them round-robin
+    int p0 = 0;
+    for (int i = 0; i < meta.n_cov; ++i) {
+        const int ki = meta.k[i], Ci = meta.lev[i], off = meta.off[i], yo = meta.yoff[i];
+        const float lam = meta.lam[i];
+        float* so = out + meta.soff[i];
+        const int items = Ci * ki + ki;
+        for (int p = (wave - p0 % 4 + 4) % 4; p < items; p += 4) {
+            float v;
+            if (p < Ci * ki) {
+                const int c = p / ki, k = p - c * ki;
+                v = zbuf[yo + c][lane] * hbuf[off + k][lane];
+                v = fmaf(zbuf[yo + c][lane + 64], hbuf[off + k][lane + 64], v);
+            } else {
+                const int k = p - Ci * ki;
+                v = lam * hbuf[off + k][lane] + lam * hbuf[off + k][lane + 64];
+            }
+            v = wave_sum_f32_dpp(v);
+            if (lane == 0) so[p] = v;                                  // [bnum: C_i x k_i][bden: k_i] are contiguous
+        }
+        p0 += items;
+        if (tid == i) {
+            const double tot = lred[2 * i] + lred[2 * i + 1];
+            const float hi = (float)tot;
+            so[Ci * ki + ki] = hi;
+            so[Ci * ki + ki + 1] = (float)(tot - (double)hi);
+        }
+    }
+}
+
 // stacked row r of Y: first column / columns of its covariate, offset of B_i[r - yoff_i][0] in the packed B, lam (Fro: 2 lam)
 struct GuidedRow { int off, k, base; float lam; };
 
@@ -1334,6 +1413,8 @@ struct HTail {
     float* stat_part;       // [groups][nstat]
     int nstat, max_k, max_ct;
     int ybuf_rows;          // rows of Y the block copies into LDS (all of them when they fit HT_YROWS_MAX, else 0 = read Y from global)
+    int merged;             // 1: the tail's statistics for all covariates in one pass (hstats_tail_merged; needs the Y copy in LDS)
+    int guided;             // sum of the k_i
     int gm;                 // 1: guided terms as two small matrix products on the MFMA (below); needs 0 < nY <= 32 and the Y copy in LDS
     int nY, kg;             // gm: rows of Y in total; guided columns rounded up to a multiple of 8
     const struct GuidedRow* rowtab;   // gm: [32] device table, stacked row of Y -> its covariate's columns / B rows / lam
@@ -1402,6 +1483,9 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     const bool with_tail = tail.gram_part != nullptr;
     const bool y_lds = tail.ybuf_rows > 0;
     HU_STAMP(0);
+    const int64_t grp = blockIdx.x;                                            // 128-cell group
+    const int64_t n0 = (grp * 4 + wave) * 32;                                  // this wave's 32 cells
+    const bool active = n0 < N;                                                // wave-uniform
     {
         // Y of this block's 128 cells: one load phase up front instead of a dependent global load per (covariate, class)
         const int64_t cell0 = (int64_t)blockIdx.x * HS_CELLS;
@@ -1418,19 +1502,19 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     HU_STAMP(1);
 
     {
-        const int64_t grp = blockIdx.x;                                        // 128-cell group
-        const int64_t n0 = (grp * 4 + wave) * 32;
-        const bool active = n0 < N;                                            // wave-uniform
         f32x4 hreg[KT][4];
         bool valid = false;
         if (active) {
             const int64_t n = n0 + c;
             valid = n < N;
+
             const int ft = (int)(n0 / g.bf), fl0 = (int)(n0 % g.bf);
             int w_lo, w_hi;
             sg_tile_pieces(g, ft, w_lo, w_hi);
 
-            // whole-row global accesses, C/D layout in registers (rows n0 .. n0+31 exist: H and the pieces are padded to 128 rows)
+            // whole-row global accesses, C/D layout in registers (rows n0 .. n0+31 exist: H and the pieces are padded to 128 rows).
+            // (Issuing the H tile and the first pieces BEFORE the fills and their barrier does not pay: loads return in order, so
+            // the fills then wait behind 24 KB per wave -- fills + pieces 8.4 -> 10.9 us at 200 000 cells in the in-kernel stamps.)
             f32x4 xreg[KT][4];
             {
                 f32x4 hraw[(32 * KT * 8) / 64];
@@ -1578,7 +1662,9 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
         gram_of_lds_tiles<KT>(trall, wave, lane, tail.gram_part + (int64_t)blockIdx.x * KP * KP);      // H H^T over the block's 128 cells
         HU_STAMP(6);
         if (meta.n_cov > 0) {
-            if (y_lds) {
+            if (y_lds && tail.merged) {
+                hstats_tail_merged(trall, LD, TRSZ, ybuf, Bl, meta, tail.stat_part + grp * tail.nstat, grp * HS_CELLS, N, eps, tail.guided, hs_smem);
+            } else if (y_lds) {
                 hstats_tail(trall, LD, TRSZ, ybuf, Bl, meta, tail.stat_part + grp * tail.nstat, grp * HS_CELLS, N, eps, tail.max_k, tail.max_ct, hs_smem);
             } else {
                 // many label levels: the stand-alone arithmetic with Y from global memory; threads 128..255 walk the same
@@ -1646,7 +1732,7 @@ void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) dacc += (double)xreg[m][q][e] * (double)wreg[m][q][e];
     if (!valid) dacc = 0.0;
-    dacc = wave_sum_f64(dacc);
+    dacc = wave_sum_f64_dpp(dacc);                       // (DPP path: six ds_bpermute round trips less on the block's critical chain)
     if (lane == 0) dotpart[gw] = dacc;
     if (!do_update) return;
 

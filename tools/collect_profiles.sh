@@ -22,4 +22,5 @@ bash tools/profile_mode.sh x3 cfg4 share8_fullsig --cells 125000 --x-scale 0.371
 bash tools/profile_mode.sh f32 cfg4 share8 --cells 125000
 unset STATS_ONLY TIMELINE_ANCHOR
 python3 bench.py > gpurun_out/prof/bench_default_cfg3.json 2> gpurun_out/prof/bench_default_cfg3.err
+ALPINE_BENCH_REHEARSAL_ONE_GPU=1 python3 bench.py --gpus 2 --steps 20 --warmup 3 > gpurun_out/prof/bench_rehearsal_2ranks_one_gpu.json 2> gpurun_out/prof/bench_rehearsal_2ranks_one_gpu.err || true
 echo "collect_profiles done"
