@@ -1,26 +1,10 @@
 #!/bin/bash
-# Everything that goes under profiles/rNN/, in one gpurun call (run from the repo root; ~15 GPU-minutes):
+# Everything that goes under profiles/rNN/, in two gpurun calls (a call is limited to 20 minutes) (run from the repo root; ~15 GPU-minutes):
 #   bash tools/collect_profiles.sh          -> gpurun_out/prof/*
 # cfg3 in every sweep mode with PMC passes (the headline + BASELINE config 5 + the full-significand leg), then kernel traces
 # and per-iteration timelines of the other shapes: one of 8 shards of cfg3 (25 000 cells), cfg2, cfg4's per-GPU share
 # (125 000 cells, K = 105) in x3 and f32, and the default bench line.
 set -e
-export TIMELINE_ANCHOR=w_update_mfma
-bash tools/profile_mode.sh x3 cfg3
-bash tools/profile_mode.sh x3 cfg3 fullsig --x-scale 0.3712345
-bash tools/profile_mode.sh f32 cfg3
-bash tools/profile_mode.sh split cfg3
-bash tools/profile_mode.sh bf16 cfg3
-export STATS_ONLY=1
-bash tools/profile_mode.sh x3 cfg3 shard8 --cells 25000
-bash tools/profile_mode.sh x3 cfg3 shard4 --cells 50000
-bash tools/profile_mode.sh x3 cfg3 shard2 --cells 100000
-bash tools/profile_mode.sh x3 cfg2
-bash tools/profile_mode.sh f32 cfg2
-bash tools/profile_mode.sh x3 cfg4 share8 --cells 125000
-bash tools/profile_mode.sh x3 cfg4 share8_fullsig --cells 125000 --x-scale 0.3712345
-bash tools/profile_mode.sh f32 cfg4 share8 --cells 125000
-unset STATS_ONLY TIMELINE_ANCHOR
-python3 bench.py > gpurun_out/prof/bench_default_cfg3.json 2> gpurun_out/prof/bench_default_cfg3.err
-ALPINE_BENCH_REHEARSAL_ONE_GPU=1 python3 bench.py --gpus 2 --steps 20 --warmup 3 > gpurun_out/prof/bench_rehearsal_2ranks_one_gpu.json 2> gpurun_out/prof/bench_rehearsal_2ranks_one_gpu.err || true
+bash tools/collect_profiles_part1.sh
+bash tools/collect_profiles_part2.sh
 echo "collect_profiles done"
