@@ -251,6 +251,7 @@ extern "C" int64_t alpine_reduce_block_floats(const alpine_config* cfg)
 }
 
 static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced, int bf = SG_BLOCK_F, int bias_pm = 0) { return sg_make_geom(F, R, slots, forced, bf, bias_pm); }
+constexpr int XCD_BIAS_MAG = 40;      // per mille: what the placement probe applies (alpine_finalize_X); more stops paying, see DESIGN.md 4.2c
 static inline int sweep_grid(const SweepGeom& g) { return (g.nwg + g.sub - 1) / g.sub; }
 
 static int gram_rows_per_wave(int64_t R, int n_cu)
@@ -368,8 +369,13 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     // pieces: nwg * maxp tiles of bf x KP floats; mini-batch views have their own geometry (alpine_batch_begin), one per
     // view size.  Sized for every tile width and every view size this ctx may use.
     auto piece_floats = [&](int bf, int64_t* capA, int64_t* capB) {
-        const SweepGeom a = make_geom(Gp, Np, slots, cfg->split_a, bf, c->xcd_bias_pm), b = make_geom(Np, Gp, slots, cfg->split_b, bf, c->xcd_bias_pm);
-        int64_t ta = (int64_t)a.nwg * a.maxp, tb = (int64_t)b.nwg * b.maxp;
+        // every even/odd bias the ctx may end up with (the placement probe of alpine_finalize_X picks -+XCD_BIAS_MAG; a bias moves the
+        // last share's boundary AND can add a piece per span: maxp depends on the longer span)
+        int64_t ta = 0, tb = 0;
+        for (int bias : {c->xcd_bias_pm, 0, -XCD_BIAS_MAG, XCD_BIAS_MAG}) {
+            const SweepGeom a = make_geom(Gp, Np, slots, cfg->split_a, bf, bias), b = make_geom(Np, Gp, slots, cfg->split_b, bf, bias);
+            ta = std::max<int64_t>(ta, (int64_t)a.nwg * a.maxp); tb = std::max<int64_t>(tb, (int64_t)b.nwg * b.maxp);
+        }
         if (c->batch_cap > 0) {
             const int64_t Bp_max = round_up(std::min<int64_t>(c->batch_cap, (int64_t)1 << 30), 128);
             for (int64_t Bp = 128; Bp <= Bp_max; Bp += 128) {
@@ -377,8 +383,6 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
                 ta = std::max<int64_t>(ta, (int64_t)va.nwg * va.maxp); tb = std::max<int64_t>(tb, (int64_t)vb.nwg * vb.maxp);
             }
         }
-        // (+ a few workgroups: alpine_debug_set_xcd_bias may move the last share's boundary)
-        ta += 4 * (int64_t)a.sub * a.maxp; tb += 4 * (int64_t)b.sub * b.maxp;
         *capA = std::max(*capA, ta * bf * KP); *capB = std::max(*capB, tb * bf * KP);
     };
     const int bf_default = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
@@ -718,9 +722,19 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         HIPCHK(c, hipMemcpyAsync(&h, c->xcc_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->xcc_of_wg0 = h;
-        const int mag = 40;                                         // per mille; more stops paying (and would push cfg3's spans past the accumulation cap)
-        const int bias = h < 0 ? 0 : ((h & 1) ? -mag : mag);        // workgroup 0 on an odd XCC: the even workgroups are the slow ones
-        if (bias != c->xcd_bias_pm) { c->xcd_bias_pm = bias; apply_sweep_geometry(c, c->sweep_bf); c->tail_valid = false; }
+        const int bias = h < 0 ? 0 : ((h & 1) ? -XCD_BIAS_MAG : XCD_BIAS_MAG);      // workgroup 0 on an odd XCC: the even workgroups are the slow ones
+        if (bias != c->xcd_bias_pm) {
+            const int old_bias = c->xcd_bias_pm;
+            c->xcd_bias_pm = bias;
+            apply_sweep_geometry(c, c->sweep_bf);
+            c->tail_valid = false;
+            // the pieces buffers were sized for this division (create_impl); never launch a geometry they do not hold
+            if ((int64_t)c->geomA.nwg * c->geomA.maxp * c->geomA.bf * c->KP > (c->transform_only ? INT64_MAX : c->piecesA_cap) ||
+                (int64_t)c->geomB.nwg * c->geomB.maxp * c->geomB.bf * c->KP > c->piecesB_cap) {
+                c->xcd_bias_pm = old_bias;
+                apply_sweep_geometry(c, c->sweep_bf);
+            }
+        }
     }
     c->x_final = true;
     return 0;
@@ -874,6 +888,12 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
 
 static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which)
 {
+    // the division about to be launched must fit the pieces buffer it writes (sized in create_impl for every division this ctx
+    // may use): an error here instead of an out-of-bounds write on the device
+    const int64_t need = (int64_t)g.nwg * g.maxp * g.bf * c->KP;
+    if (need > (which == 0 ? c->piecesA_cap : c->piecesB_cap) || (which == 0 && c->transform_only))
+        return fail(c, ALPINE_ERR_STATE, "internal: sweep %d needs %lld floats of pieces, the buffer holds %lld", which, (long long)need,
+                    (long long)(which == 0 ? c->piecesA_cap : c->piecesB_cap));
     if (c->bf16) return launch_sweep_bf16(c, which, g);
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
     if (c->x3) {

@@ -37,6 +37,15 @@ def make_case(seed):
     n_cov = int(rng.integers(0, 4))
     ks = [int(rng.integers(1, 9)) for _ in range(n_cov)]
     levels = [int(rng.choice([1, 2, 3, 4, 7, 12, 20])) for _ in range(n_cov)]
+    if seed >= 5000 and n_cov:
+        # round 3 (own generator: the cases of the earlier seed ranges stay what they were): covariates WITHOUT guided components
+        # (k_i = 0) and guidance wider than 64 components in total (guided columns in every 32-column tile of H)
+        rng2 = np.random.default_rng(seed + 7777)
+        u = rng2.random()
+        if u < 0.3:
+            ks[int(rng2.integers(0, n_cov))] = 0
+        elif u < 0.55:
+            ks = [int(rng2.integers(20, 45)) for _ in range(n_cov)]
     Ku = int(rng.choice([1, 3, 8, 20, 31, 32, 33, 50, 64, 65, 90, 100, 110]))
     Ku = max(1, min(Ku, 128 - sum(ks)))
     loss = ["kl-divergence", "frobenius"][int(rng.integers(0, 2))]

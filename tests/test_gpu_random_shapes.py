@@ -233,3 +233,17 @@ def test_forced_small_lds_limit_equals_the_default_path(monkeypatch):
     for mode in ("x3", "f32"):
         assert rel_fro(a[mode][0], b[mode][0]) < 2e-6 and rel_fro(a[mode][1], b[mode][1]) < 2e-6
         assert not (np.array_equal(a[mode][0], b[mode][0]) and np.array_equal(a[mode][1], b[mode][1]))      # the knob did change the launch structure
+
+
+@pytest.mark.parametrize("seed", [3465])
+def test_fuzz_regressions(seed):
+    """Cases that tests/fuzz_gpu.py found, replayed whole (every sweep mode against the oracle, float64 arbiter, mini-batch leg).
+    3465 (round 3): G = 2047, N = 5362, K = 102, one forced share per tile -- 11 shares of exactly one tile; the even/odd span bias
+    then needs a 12th workgroup AND a third piece per span, which the pieces buffer (sized for the unbiased division plus a margin)
+    did not hold: an out-of-bounds write on the device.  The buffers are now sized for every division the ctx may use and
+    launch_sweep refuses a division that does not fit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_gpu as fz
+    fz.run_case(seed)
