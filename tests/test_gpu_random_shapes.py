@@ -1,6 +1,8 @@
 """Randomised shapes through the C ABI against the CPU oracle (fused form = the kernels' numerical spec): ragged G / N
 (not multiples of any tile), K from 1 to ~100, 0-2 covariates with 1-4 levels, both loss types, regularisers on/off,
 several stream-K span sizes; float32 MFMA, the x3 plane-product sweeps and (on integer data) the exact-split path.  Two MU steps + loss rows each."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -232,7 +234,8 @@ def test_forced_small_lds_limit_equals_the_default_path(monkeypatch):
                        env={"ALPINE_HIP_LDS_LIMIT": "26000"}, monkeypatch=monkeypatch)
     for mode in ("x3", "f32"):
         assert rel_fro(a[mode][0], b[mode][0]) < 2e-6 and rel_fro(a[mode][1], b[mode][1]) < 2e-6
-        assert not (np.array_equal(a[mode][0], b[mode][0]) and np.array_equal(a[mode][1], b[mode][1]))      # the knob did change the launch structure
+        if os.environ.get("ALPINE_HIP_H_UPDATE") != "valu":       # (the knob matrix also runs this file with the VALU form of the H update, which has no tail)
+            assert not (np.array_equal(a[mode][0], b[mode][0]) and np.array_equal(a[mode][1], b[mode][1]))      # the knob did change the launch structure
 
 
 @pytest.mark.parametrize("seed", [3465])
