@@ -61,3 +61,31 @@ def test_bench_gpus_2_launches_its_own_workers():
     assert d["config"]["parallelism"] == "cells/2" and d["config"]["cells_per_gpu"] in (2496, 2504)
     ar = d["allreduce"]
     assert ar is not None and ar["avg_ms_on_rank0"] > 0 and ar["bytes"] > 0 and ar["carrier"]
+
+
+def test_bench_under_the_drivers_launcher_command():
+    """The driver's N > 1 invocation verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the
+    launcher, rank 0 prints the one JSON line, the other rank prints nothing on stdout.  On a one-GPU box the rehearsal switch puts both
+    ranks on cuda:0 with gloo carrying the reduce block; with two GPUs it runs as the driver runs it (RCCL, one device per rank)."""
+    import socket
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        env["ALPINE_BENCH_REHEARSAL_ONE_GPU"] = "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "4", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["config"]["cells_per_gpu_by_rank"] == [d["config"]["cells_per_gpu"], 5000 - d["config"]["cells_per_gpu"]]
+    ar = d["allreduce"]
+    for key in ("first_call_ms", "first_full_block_ms", "standalone_ms", "avg_ms_on_rank0", "bytes", "carrier"):
+        assert key in ar and ar[key], key
+    assert d["rccl_version"]
