@@ -884,3 +884,26 @@ def test_out_of_memory_is_reported_as_such_and_leaves_the_device_usable():
     eng.run(2, with_loss=True)
     assert np.isfinite(eng.losses()).all()
     eng.close()
+
+
+def test_placement_probe_and_graph_replay_are_result_neutral():
+    """Round 3 diagnostics that must not change results: (i) alpine_finalize_X reads from one launch of the sweep kernel on which XCC its
+    workgroup 0 runs and derives the even/odd span bias from it (alpine_info reports both); the division is a static function of blockIdx, so
+    two engines agree bitwise; (ii) alpine_debug_run_graph replays the steady-state iteration from a hipGraph of two: same factors as the
+    eager loop, bitwise (same kernels, same order)."""
+    c = load_case("mid_counts")
+    eng = make_engine(c, x_dtype="x3")
+    info = eng.info()
+    assert 0 <= info.xcc_of_workgroup0 < 8 and abs(info.xcd_bias_per_mille) in (0, 40)
+    assert (info.xcc_of_workgroup0 & 1) == (1 if info.xcd_bias_per_mille < 0 else 0) or info.xcd_bias_per_mille == 0
+    assert info.span_rows_a <= 16384 and info.span_rows_b <= 16384
+    eng.run(2 + 2 * 3, with_loss=False)                 # what alpine_debug_run_graph(3) runs: 2 eager iterations, then 3 replays of 2
+    W1, H1, B1 = eng.get_factors()
+    eng.close()
+    eng = make_engine(c, x_dtype="x3")
+    eng.debug_run_graph(3)
+    W2, H2, B2 = eng.get_factors()
+    eng.close()
+    assert np.array_equal(W1, W2) and np.array_equal(H1, H2)
+    for a, b in zip(B1, B2):
+        assert np.array_equal(a, b)
