@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "kernels_bf16.hpp"
 #include "kernels_x3.hpp"
+#include "kernels_wide.hpp"
 
 #include <rccl/rccl.h>
 
@@ -34,6 +35,9 @@ struct CellView {
 struct alpine_ctx {
     // geometry
     int G = 0, N = 0, K = 0, KP = 0, KT = 0, n_cov = 0;
+    // wide model (128 < K <= 256, kernels_wide.hpp): KP = 256, KT = 4 = tiles per HALF, factors in the blocked layout [2][rows][128]
+    bool wide = false;
+    float *wide_den = nullptr, *wide_num = nullptr;     // [2][max(Gp, Np)][128] product A.M of the updates; [2][Np][128] transform numerator
     int64_t Gp = 0, Np = 0;
     std::vector<int> cov_k, cov_lev;
     std::vector<double> lam;
@@ -228,12 +232,20 @@ static int geometry(const alpine_config* cfg, Geometry* g, std::string* why)
         nB += C * k;
         nY += C;
     }
-    if (K > 128) { *why = "total components > 128 not supported by this build"; return -1; }
+    if (K > 256) { *why = "total components > 256 not supported by this build"; return -1; }
+    if (K > 128) {
+        int guided = 0;
+        for (int i = 0; i < cfg->n_covariates; ++i) guided += cfg->cov_components[i];
+        if (guided > 128) { *why = "with more than 128 components in total the guided ones must fit in the first 128 columns (sum k_i <= 128)"; return -1; }
+        if (cfg->flags & (ALPINE_FLAG_X_BF16 | ALPINE_FLAG_X_SPLIT)) { *why = "more than 128 components need the float32 storage (x3 or f32 sweeps)"; return -1; }
+        if (cfg->flags & ALPINE_FLAG_USE_ALS) { *why = "the block-coordinate branch supports at most 128 components in this build"; return -1; }
+        if (cfg->batch_capacity > 0) { *why = "mini-batches support at most 128 components in this build"; return -1; }
+    }
     if (cfg->loss_type != ALPINE_LOSS_KL && cfg->loss_type != ALPINE_LOSS_FROBENIUS) { *why = "loss_type must be one of ['kl-divergence', 'frobenius']."; return -1; }
     if (!(cfg->eps >= 0) || !(cfg->alpha_W >= 0) || !(cfg->orth_W >= 0) || !(cfg->l1_ratio_W >= 0 && cfg->l1_ratio_W <= 1)) { *why = "eps/alpha_W/orth_W must be >= 0 and l1_ratio_W in [0,1]"; return -1; }
     g->K = K;
-    g->KT = (K + 31) / 32;
-    g->KP = 32 * g->KT;
+    g->KT = K > 128 ? WIDE_KT : (K + 31) / 32;          // wide: tiles per half
+    g->KP = K > 128 ? 2 * WIDE_KH : 32 * g->KT;
     g->nstat = nstat; g->nB = nB; g->nYrows = nY;
     g->Gp = round_up(cfg->n_genes, 128);
     g->Np = round_up(cfg->n_cells, 128);
@@ -275,6 +287,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
 {
     c->G = (int)cfg->n_genes; c->N = (int)cfg->n_cells;
     c->K = g.K; c->KP = g.KP; c->KT = g.KT; c->Gp = g.Gp; c->Np = g.Np;
+    c->wide = g.K > 128;
     c->n_cov = cfg->n_covariates;
     c->nstat = g.nstat; c->nB = g.nB; c->nYrows = g.nYrows;
     c->orth = cfg->orth_W; c->alpha = cfg->alpha_W; c->l1r = cfg->l1_ratio_W; c->eps = cfg->eps;
@@ -409,6 +422,10 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     }
     ALLOC(c, c->W, float, Gp * KP);
     ALLOC(c, c->H, float, Np * KP);
+    if (c->wide) {
+        ALLOC(c, c->wide_den, float, std::max(Gp, Np) * KP);
+        ALLOC(c, c->wide_num, float, Np * KP);
+    }
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
     ALLOC(c, c->B[0], float, std::max(1, c->nB));
     ALLOC(c, c->B[1], float, std::max(1, c->nB));
@@ -494,7 +511,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->rowtab, c->xcc_dev, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->rowtab, c->xcc_dev, c->wide_den, c->wide_num, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -761,20 +778,25 @@ extern "C" int alpine_set_factors(alpine_ctx* c, const float* W, const float* H,
     HIPCHK(c, hipSetDevice(c->device));
     const int K = c->K, KP = c->KP;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // W: G x K -> [Gp][KP]
+    // W: G x K -> [Gp][KP]   (wide: column half h -> [h][Gp][128])
+    const int halves = c->wide ? 2 : 1, kph = c->wide ? WIDE_KH : KP;
     HIPCHK(c, hipMemsetAsync(c->W, 0, sizeof(float) * c->Gp * KP, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->stage, W, sizeof(float) * (size_t)c->G * K, hipMemcpyHostToDevice, c->stream));
-    {
-        const int64_t n = (int64_t)c->G * K;
-        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->stage, (int64_t)K, c->W, KP, (int64_t)c->G, K);
+    for (int h = 0; h < halves; ++h) {
+        const int kh = std::min(kph, K - h * kph);
+        const int64_t n = (int64_t)c->G * kh;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->stage + h * kph, (int64_t)K,
+                           c->W + (int64_t)h * c->Gp * kph, kph, (int64_t)c->G, kh);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // H: K x N (ldH) -> [Np][KP] cell-major
+    // H: K x N (ldH) -> [Np][KP] cell-major   (wide: row block h of H -> [h][Np][128])
     HIPCHK(c, hipMemsetAsync(c->H, 0, sizeof(float) * c->Np * KP, c->stream));
     HIPCHK(c, hipMemcpy2DAsync(c->stage, sizeof(float) * c->N, H, sizeof(float) * ldH, sizeof(float) * c->N, (size_t)K, hipMemcpyHostToDevice, c->stream));
-    {
-        dim3 grid((unsigned)((c->N + 31) / 32), (K + 31) / 32);
-        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->stage, (int64_t)c->N, c->H, (int64_t)KP, K, c->N);
+    for (int h = 0; h < halves; ++h) {
+        const int kh = std::min(kph, K - h * kph);
+        dim3 grid((unsigned)((c->N + 31) / 32), (kh + 31) / 32);
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->stage + (int64_t)h * kph * c->N, (int64_t)c->N,
+                           c->H + (int64_t)h * c->Np * kph, (int64_t)kph, kh, c->N);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bcur = 0;
@@ -798,15 +820,24 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
     if ((H && ldH < c->N)) return fail(c, ALPINE_ERR_BAD_ARG, "ldH too small");
     HIPCHK(c, hipSetDevice(c->device));
     const int K = c->K, KP = c->KP;
+    const int halves = c->wide ? 2 : 1, kph = c->wide ? WIDE_KH : KP;
     if (W) {
-        const int64_t n = (int64_t)c->G * K;
-        hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->W, KP, c->stage, (int64_t)K, (int64_t)c->G, K);
-        HIPCHK(c, hipMemcpyAsync(W, c->stage, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+        for (int h = 0; h < halves; ++h) {
+            const int kh = std::min(kph, K - h * kph);
+            const int64_t n = (int64_t)c->G * kh;
+            hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->W + (int64_t)h * c->Gp * kph, kph,
+                               c->stage + h * kph, (int64_t)K, (int64_t)c->G, kh);
+        }
+        HIPCHK(c, hipMemcpyAsync(W, c->stage, sizeof(float) * (size_t)c->G * K, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (H) {
-        dim3 grid((K + 31) / 32, (unsigned)((c->N + 31) / 32));
-        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->H, (int64_t)KP, c->stage, (int64_t)c->N, c->N, K);
+        for (int h = 0; h < halves; ++h) {
+            const int kh = std::min(kph, K - h * kph);
+            dim3 grid((kh + 31) / 32, (unsigned)((c->N + 31) / 32));
+            hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->H + (int64_t)h * c->Np * kph, (int64_t)kph,
+                               c->stage + (int64_t)h * kph * c->N, (int64_t)c->N, c->N, kh);
+        }
         HIPCHK(c, hipMemcpy2DAsync(H, sizeof(float) * ldH, c->stage, sizeof(float) * c->N, sizeof(float) * c->N, (size_t)K, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -890,8 +921,8 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
 {
     // the division about to be launched must fit the pieces buffer it writes (sized in create_impl for every division this ctx
     // may use): an error here instead of an out-of-bounds write on the device
-    const int64_t need = (int64_t)g.nwg * g.maxp * g.bf * c->KP;
-    if (need > (which == 0 ? c->piecesA_cap : c->piecesB_cap) || (which == 0 && c->transform_only))
+    const int64_t need = (int64_t)g.nwg * g.maxp * g.bf * (c->wide ? WIDE_KH : c->KP);        // (wide: one pass = one half of the buffer)
+    if (need > (which == 0 ? c->piecesA_cap : c->piecesB_cap) / (c->wide ? 2 : 1) || (which == 0 && c->transform_only))
         return fail(c, ALPINE_ERR_STATE, "internal: sweep %d needs %lld floats of pieces, the buffer holds %lld", which, (long long)need,
                     (long long)(which == 0 ? c->piecesA_cap : c->piecesB_cap));
     if (c->bf16) return launch_sweep_bf16(c, which, g);
@@ -902,7 +933,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         if (c->ablate_flush) gx.panel_fixed = 2;
         else if (c->ablate_panel) gx.panel_fixed = 1;
         if (c->x3_wide && !c->x3_ablate) {
-            const bool pad_tile = c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
+            const bool pad_tile = !c->wide && c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
 #define X3W_LAUNCH(KT_, NH_) do { \
                 if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); \
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); } while (0)
@@ -948,11 +979,12 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     return 0;
 }
 
-static int launch_reduce_pieces(alpine_ctx* c, const float* pieces, float* out, int rows, const SweepGeom& g)
+static int launch_reduce_pieces(alpine_ctx* c, const float* pieces, float* out, int rows, const SweepGeom& g, int kp = 0)
 {
-    const int64_t n4 = (int64_t)rows * c->KP / 4;
+    if (kp == 0) kp = c->KP;
+    const int64_t n4 = (int64_t)rows * kp / 4;
     const int blocks = (int)std::min<int64_t>(c->n_cu * 8, (n4 + 255) / 256);
-    hipLaunchKernelGGL(reduce_pieces_kernel, dim3(std::max(1, blocks)), dim3(256), 0, c->stream, pieces, out, rows, c->KP, g);
+    hipLaunchKernelGGL(reduce_pieces_kernel, dim3(std::max(1, blocks)), dim3(256), 0, c->stream, pieces, out, rows, kp, g);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1244,12 +1276,146 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------- wide models (128 < K <= 256, kernels_wide.hpp)
+static float* wide_half(float* base, int64_t rows_pad, int h) { return base + (int64_t)h * rows_pad * WIDE_KH; }
+static float* wide_block(float* base, int a, int b) { return base + (int64_t)(a * 2 + b) * WIDE_KH * WIDE_KH; }
+
+// out (blocked [2][2][128][128]) = A^T A for a blocked A [2][R][128]
+static int launch_gram_wide(alpine_ctx* c, float* A, int64_t R, float* out)
+{
+    const int rpw = gram_rows_per_wave(R, c->n_cu);
+    const int blocks = (int)((R + 4 * rpw - 1) / (4 * rpw));
+    if (blocks > c->gramPart_cap) return fail(c, ALPINE_ERR_STATE, "internal: Gram partial buffer too small");
+    const int n = WIDE_KH * WIDE_KH;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            hipLaunchKernelGGL(gram_cross_kernel<WIDE_KT>, dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw);
+            hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, wide_block(out, a, b), n, blocks);
+        }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int launch_wide_den(alpine_ctx* c, const float* A, int64_t rows_pad, const float* G, int mode, int k_lo, int k_hi, bool block_orth)
+{
+    WideDenArgs a{};
+    a.rows_pad = (int)rows_pad; a.K = c->K; a.mode = mode;
+    a.orth = (float)c->orth; a.l2 = (float)((1.0 - c->l1r) * c->alpha);
+    a.k_lo = k_lo; a.k_hi = k_hi; a.block_orth = block_orth ? 1 : 0;
+    const size_t lds = sizeof(float) * (WIDE_KH * WIDE_KH + 4 * 32 * (WIDE_KH + 4));
+    hipLaunchKernelGGL(wide_den_kernel, dim3((unsigned)(rows_pad / 128)), dim3(256), lds, c->stream, A, G, c->wide_den, a);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int phase1_wide(alpine_ctx* c)
+{
+    int rc;
+    const CellView& v = c->full;
+    c->prof_now = c->prof && (c->prof_tick++ % c->prof_every) == 0;
+    int max_k, max_ct;
+    cov_maxima(c, &max_k, &max_ct);
+    if (c->n_cov > 0) {
+        hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hstats_group_bytes(max_k, max_ct), c->stream, c->H, c->Y, c->B[c->bcur],
+                           c->meta, c->statPart, c->N, c->Np, WIDE_KH, (float)c->eps, c->nstat, max_k, max_ct);       // guided components: first half
+        HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,
+                       v.statBlocks, c->nstat, c->xnorm2);
+    HIPCHK(c, hipGetLastError());
+    if ((rc = launch_gram_wide(c, c->H, c->Np, c->red + c->red_hht))) return rc;
+    for (int h = 0; h < 2; ++h) {
+        float* pieces = c->piecesA + h * (c->piecesA_cap / 2);
+        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
+        if ((rc = launch_sweep(c, v.gA, c->Xng, wide_half(c->H, c->Np, h), pieces, 0))) return rc;
+        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
+        if ((rc = launch_reduce_pieces(c, pieces, wide_half(c->red, c->Gp, h), (int)c->Gp, v.gA, WIDE_KH))) return rc;
+    }
+    return 0;
+}
+
+static int wide_h_apply(alpine_ctx* c, const float* num_in, bool guided)
+{
+    CovMeta meta = c->meta;
+    if (!guided) meta.n_cov = 0;
+    const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)c->N + 3) / 4);
+    const float* p0 = c->piecesB;
+    const float* p1 = c->piecesB + c->piecesB_cap / 2;
+    if (c->loss_type == ALPINE_LOSS_KL)
+        hipLaunchKernelGGL(wide_h_apply_kernel<0>, dim3(blocks), dim3(256), 0, c->stream, c->H, c->wide_den, p0, p1, c->geomB, num_in, c->Y, c->B[c->bcur], meta,
+                           c->N, c->Np, c->K, (float)c->eps, 0, c->K, -1);
+    else
+        hipLaunchKernelGGL(wide_h_apply_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, c->H, c->wide_den, p0, p1, c->geomB, num_in, c->Y, c->B[c->bcur], meta,
+                           c->N, c->Np, c->K, (float)c->eps, 0, c->K, -1);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int grow_losses(alpine_ctx* c);
+
+// [loss row of the factors that produced the reduce block], W update, B updates, W^TW, W^TX sweeps, H update: the unfused sequence of
+// phase2 with every K-templated kernel replaced by its blocked form
+static int phase2_wide(alpine_ctx* c, bool update, bool finalize)
+{
+    int rc;
+    float* HHt = c->red + c->red_hht;
+    const float l1 = (float)(c->l1r * c->alpha);
+    if (update && (rc = launch_wide_den(c, c->W, c->Gp, HHt, 0, 0, c->K, false))) return rc;
+    hipLaunchKernelGGL(wide_w_apply_kernel, dim3(c->ndot), dim3(256), 0, c->stream, c->W, c->red, c->wide_den, c->dotpart, c->G, c->Gp, c->K, l1,
+                       (float)c->eps, update ? 1 : 0, 0, c->K);
+    HIPCHK(c, hipGetLastError());
+    if (finalize) {
+        if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, HHt, c->red + c->red_stats, c->meta,
+                           c->nstat, c->KP, c->lam_dev, c->loss_dev + c->loss_rows * (c->n_cov + 2));
+        HIPCHK(c, hipGetLastError());
+        c->loss_rows++;
+    }
+    if (!update) return 0;
+    if (c->n_cov > 0) {
+        hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
+                           wide_block(HHt, 0, 0), c->meta, WIDE_KH, (float)c->eps);                                    // guided components: block (0, 0)
+        HIPCHK(c, hipGetLastError());
+        c->bcur ^= 1;
+    }
+    if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
+    for (int h = 0; h < 2; ++h) {
+        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+        if ((rc = launch_sweep(c, c->geomB, c->Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1))) return rc;
+        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    }
+    if ((rc = launch_wide_den(c, c->H, c->Np, c->WtW, 1, 0, c->K, false))) return rc;
+    if ((rc = wide_h_apply(c, nullptr, true))) return rc;
+    c->tail_valid = false;
+    return 0;
+}
+
+static int transform_wide(alpine_ctx* c, int n_iter)
+{
+    int rc;
+    if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
+    for (int h = 0; h < 2; ++h) {
+        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+        if ((rc = launch_sweep(c, c->geomB, c->Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1))) return rc;
+        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    }
+    const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)c->N + 3) / 4);
+    hipLaunchKernelGGL(wide_num_kernel, dim3(blocks), dim3(256), 0, c->stream, c->wide_num, c->piecesB, c->piecesB + c->piecesB_cap / 2, c->geomB, c->N, c->Np);
+    HIPCHK(c, hipGetLastError());
+    for (int it = 0; it < n_iter; ++it) {
+        if ((rc = launch_wide_den(c, c->H, c->Np, c->WtW, 1, 0, c->K, false))) return rc;
+        if ((rc = wide_h_apply(c, c->wide_num, false))) return rc;
+    }
+    return 0;
+}
+
 extern "C" int alpine_iter_begin(alpine_ctx* c)
 {
     int rc = ready(c);
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
-    return phase1(c, c->full);
+    return c->wide ? phase1_wide(c) : phase1(c, c->full);
 }
 
 extern "C" int alpine_iter_end(alpine_ctx* c, int update)
@@ -1257,7 +1423,8 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
     int rc = ready(c);
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
-    rc = phase2(c, c->full, update != 0, c->pending_loss && c->loss_enabled);
+    rc = c->wide ? phase2_wide(c, update != 0, c->pending_loss && c->loss_enabled)
+                 : phase2(c, c->full, update != 0, c->pending_loss && c->loss_enabled);
     if (rc) return rc;
     c->pending_loss = update != 0;
     return 0;
@@ -1509,6 +1676,7 @@ extern "C" int alpine_epoch_loss_begin(alpine_ctx* c)
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
     if (c->batch_open) return fail(c, ALPINE_ERR_STATE, "alpine_epoch_loss_begin inside an open batch");
+    if (c->wide) return fail(c, ALPINE_ERR_UNSUPPORTED, "mini-batch epochs support at most 128 components in this build");
     if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
     return phase1(c, c->full);
 }
@@ -1537,6 +1705,12 @@ extern "C" int alpine_transform(alpine_ctx* c, int n_iter)
     if (rc) return rc;
     if (n_iter < 0) return fail(c, ALPINE_ERR_BAD_ARG, "n_iter must be >= 0");
     const int KP = c->KP;
+    if (c->wide) {
+        if ((rc = transform_wide(c, n_iter))) return rc;
+        c->pending_loss = false;
+        c->tail_valid = false;
+        return 0;
+    }
     if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
     if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
     if ((rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB, 1))) return rc;
@@ -1593,15 +1767,21 @@ extern "C" int alpine_scale(alpine_ctx* c)
 {
     int rc = ready(c);
     if (rc) return rc;
-    const int KP = c->KP, K = c->K;
     const int rows_per_block = 256;
     const int nblk = (c->G + rows_per_block - 1) / rows_per_block;
+    const int halves = c->wide ? 2 : 1, KP = c->wide ? WIDE_KH : c->KP;          // (wide: one half of the blocked factors at a time)
     if ((int64_t)nblk * KP > c->f64part_n) return fail(c, ALPINE_ERR_UNSUPPORTED, "too many genes for the scaling scratch");
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(nblk), dim3(256), 0, c->stream, c->W, KP, c->G, rows_per_block, c->f64part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, c->stream, c->f64part, nblk, KP, c->scale);
-    const int64_t nw = (int64_t)c->G * K, nh = (int64_t)c->N * K;
-    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, c->stream, c->W, KP, (int64_t)c->G, K, c->scale, 1);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, c->stream, c->H, KP, (int64_t)c->N, K, c->scale, 0);
+    for (int h = 0; h < halves; ++h) {
+        const int K = std::min(KP, c->K - h * KP);
+        float* Wh = c->W + (int64_t)h * c->Gp * KP;
+        float* Hh = c->H + (int64_t)h * c->Np * KP;
+        float* sc = c->scale + h * KP;
+        hipLaunchKernelGGL(colsum_part_kernel, dim3(nblk), dim3(256), 0, c->stream, Wh, KP, c->G, rows_per_block, c->f64part);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, c->stream, c->f64part, nblk, KP, sc);
+        const int64_t nw = (int64_t)c->G * K, nh = (int64_t)c->N * K;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, c->stream, Wh, KP, (int64_t)c->G, K, sc, 1);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, c->stream, Hh, KP, (int64_t)c->N, K, sc, 0);
+    }
     if (c->n_cov > 0) hipLaunchKernelGGL(scale_b_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->meta, c->scale);
     HIPCHK(c, hipGetLastError());
     c->pending_loss = false;      // W^TW / reduce terms no longer describe these factors
@@ -1631,6 +1811,12 @@ extern "C" int alpine_eval_recon_direct(alpine_ctx* c, double* out)
     int cells_per_block = 256;
     while ((int64_t)gx * ((Bn + cells_per_block - 1) / cells_per_block) > c->f64part_n) cells_per_block *= 2;
     const int gy = (Bn + cells_per_block - 1) / cells_per_block;
+    if (c->wide) {
+        if (swap) hipLaunchKernelGGL(eval_recon_wide_kernel, dim3(gx, gy), dim3(256), 0, c->stream, c->Xgn, c->Np, c->H, c->Np, c->W, c->Gp, A, Bn, cells_per_block, c->f64part);
+        else hipLaunchKernelGGL(eval_recon_wide_kernel, dim3(gx, gy), dim3(256), 0, c->stream, c->Xng, c->Gp, c->W, c->Gp, c->H, c->Np, A, Bn, cells_per_block, c->f64part);
+        HIPCHK(c, hipGetLastError());
+        return sum_f64_partials(c, gx * gy, out);
+    }
     if (swap) {
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(eval_recon_kernel<KT_>, dim3(gx, gy), dim3(256), 0, c->stream, c->Xgn, c->Np, c->H, c->W,
                                                A, Bn, cells_per_block, c->f64part));

@@ -57,6 +57,9 @@ WORKLOADS = {
     "tiny": dict(genes=2000, cells=5000, ku=20, kcov=[2], alpha_W=0.0, orth_W=0.0, l1_ratio_W=0.0),
     # cfg3's matrix with K = 22 + [5, 5] = 32 (one MFMA tile of components): the shape at which the x3 kernels fit two waves per SIMD
     "cfg3_k32": dict(genes=20000, cells=200000, ku=22, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
+    # cfg3's matrix with K = 140 + [5, 5] = 150 and K = 246 + [5, 5] = 256: the blocked two-half path for 128 < K <= 256 (kernels_wide.hpp)
+    "cfg3_k150": dict(genes=20000, cells=200000, ku=140, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
+    "cfg3_k256": dict(genes=20000, cells=200000, ku=246, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
 }
 
 

@@ -191,6 +191,13 @@ CASES = [
     dict(name="als_guided_wide", n_cells=150, n_genes=90, seed=35, T=5,
          covariates=[("c1", ["x", "y", "z"], 0.0), ("c2", ["p", "q"], 0.0)],
          params=dict(n_components=10, n_covariate_components=[40, 30], lam=[1e3, 5e2], use_als=True, orth_W=0.05)),
+    # more than 128 components in total (the build's blocked two-half path, kernels_wide.hpp)
+    dict(name="wide_k150", transform_iters=5, n_cells=120, n_genes=100, seed=36, T=6,
+         covariates=[("c1", ["x", "y", "z"], 0.05), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=140, n_covariate_components=[6, 4], lam=[1e3, 2e2], orth_W=0.05, alpha_W=0.3, l1_ratio_W=0.5)),
+    dict(name="wide_k200_fro", n_cells=130, n_genes=90, seed=37, T=5,
+         covariates=[("c1", ["x", "y"], 0.0)],
+         params=dict(n_components=190, n_covariate_components=[10], lam=[4.0], loss_type="frobenius")),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,
@@ -280,7 +287,7 @@ def run_case(case: dict, AnnData, out_dir: str):
           f"loss[-1]={out['loss_history'][-1].tolist()}")
 
 
-POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov", "many_levels", "fro_3cov"]
+POSTHOC_CASES = ["kl_1cov", "kl_2cov_nan", "fro_2cov_reg", "counts_2cov", "many_levels", "fro_3cov", "k0_split", "wide_k150"]
 
 
 def run_posthoc(case: dict, AnnData, out_dir: str):

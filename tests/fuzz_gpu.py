@@ -48,6 +48,11 @@ def make_case(seed):
             ks = [int(rng2.integers(20, 45)) for _ in range(n_cov)]
     Ku = int(rng.choice([1, 3, 8, 20, 31, 32, 33, 50, 64, 65, 90, 100, 110]))
     Ku = max(1, min(Ku, 128 - sum(ks)))
+    if seed >= 7000 and np.random.default_rng(seed + 4242).random() < 0.35:
+        # wide models (128 < K <= 256: the blocked two-half path); guided components stay within the first 128 columns
+        ks = [min(k, 40) for k in ks]
+        Ku = int(np.random.default_rng(seed + 4243).integers(129 - min(sum(ks), 128), 257 - sum(ks)))
+        G = min(G, 1500)
     loss = ["kl-divergence", "frobenius"][int(rng.integers(0, 2))]
     reg = bool(rng.integers(0, 2))
     kind = str(rng.choice(["counts", "counts_big", "gamma", "scaled_counts", "sparse"]))
@@ -125,7 +130,7 @@ def run_case(seed):
     t0 = time.perf_counter()
     orc.fit_fused(p, s, iters, with_loss=True)
     t_or = time.perf_counter() - t0
-    modes = ["f32", "x3"] + (["split"] if kind in ("counts", "counts_big") and float(X.max()) < 65536 else [])
+    modes = ["f32", "x3"] + (["split"] if kind in ("counts", "counts_big") and float(X.max()) < 65536 and p.total_components <= 128 else [])
     out = []
     cache = {}
 
@@ -170,7 +175,7 @@ def run_case(seed):
         out.append(f"{mode}:{eW:.1e}/{eH:.1e}")
     # now and then: block-coordinate branch / mini-batches against the op-for-op oracle on the same data
     extra = ""
-    if p.n_covariate_components and N <= 6000 and rng.random() < 0.5:
+    if p.n_covariate_components and N <= 6000 and rng.random() < 0.5 and p.total_components <= 128:
         use_als = bool(rng.integers(0, 2))
         p.use_als = use_als
         bs = int(rng.integers(max(2, N // 5), N + 1))

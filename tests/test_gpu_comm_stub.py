@@ -61,7 +61,7 @@ def _check_against_golden(c, r, local):
     return H
 
 
-@pytest.mark.parametrize("case_name,local", [("kl_2cov_nan", False), ("counts_2cov", True), ("fro_2cov_reg", False)])
+@pytest.mark.parametrize("case_name,local", [("kl_2cov_nan", False), ("counts_2cov", True), ("fro_2cov_reg", False), ("wide_k200_fro", False)])
 def test_native_loop_two_ranks_full_batch(case_name, local, tmp_path):
     """alpine_run with a two-rank communicator: one exchange of the whole reduce block per iteration (+ one for the last
     loss row).  Equal to the single-device run up to the summation order of the two shards."""

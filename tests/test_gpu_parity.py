@@ -65,6 +65,11 @@ def test_reduce_block_matches_numpy(name):
     blk = eng.read_buffer(nat.BUF_REDUCE_BLOCK, 0, info.reduce_block_floats)
     XHt = blk[: info.genes_padded * KP].reshape(info.genes_padded, KP)
     HHt = blk[info.genes_padded * KP: info.genes_padded * KP + KP * KP].reshape(KP, KP)
+    if K > 128:
+        # wide models keep their factors as two column halves (kernels_wide.hpp): XH^T is [2][Gp][128], H H^T four 128 x 128 blocks
+        XHt = np.concatenate(list(blk[: info.genes_padded * KP].reshape(2, info.genes_padded, 128)), axis=1)
+        b4 = blk[info.genes_padded * KP: info.genes_padded * KP + KP * KP].reshape(2, 2, 128, 128)
+        HHt = np.block([[b4[0, 0], b4[0, 1]], [b4[1, 0], b4[1, 1]]])
     X64, H64 = c.X.T.astype(np.float64), c.H0.astype(np.float64)
     assert rel_fro(XHt[:G, :K], X64 @ H64.T) < 2e-6
     assert rel_fro(HHt[:K, :K], H64 @ H64.T) < 2e-6
@@ -303,10 +308,14 @@ def test_errors_are_loud():
         eng.run(1)                     # nothing uploaded yet
     eng.close()
     with pytest.raises(nat.AlpineNativeError):
-        nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0])
+        nat.NativeShard(n_genes=64, n_cells=96, n_components=255, cov_components=[2], cov_levels=[2], lam=[1.0])       # K = 257 > 256
+    with pytest.raises(nat.AlpineNativeError, match="block-coordinate branch supports at most 128"):
+        nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0], use_als=True)
+    with pytest.raises(nat.AlpineNativeError, match="mini-batches support at most 128"):
+        nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0], batch_capacity=32)
 
 
-TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74"]
+TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74", "k0_split", "guided_wide", "wide_k150"]
 
 
 @pytest.mark.parametrize("name", TRANSFORM_CASES)

@@ -250,3 +250,16 @@ def test_fuzz_regressions(seed):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fuzz_gpu as fz
     fz.run_case(seed)
+
+
+@pytest.mark.parametrize("Ku,ks,levels,loss,reg", [
+    (129, [], [], "kl-divergence", False),               # one component in the second half
+    (150, [5, 4], [3, 2], "kl-divergence", True),
+    (120, [60, 60], [2, 4], "frobenius", True),           # K = 240, the guided components fill 120 of the first half's 128 columns
+    (256, [], [], "frobenius", False),                    # the largest model: both halves full
+    (200, [0, 7], [2, 3], "kl-divergence", False),
+])
+def test_wide_models_vs_oracle(Ku, ks, levels, loss, reg):
+    """128 < K <= 256: the blocked two-half path (kernels_wide.hpp; every update as den = A.M on the MFMA + an elementwise apply, the
+    sweeps once per half) against the oracle's fused iteration, ragged G and N, x3 and f32 sweeps, loss rows included."""
+    _fit_vs_oracle(300 + Ku, G=203, N=517, Ku=Ku, ks=ks, levels=levels, loss=loss, iters=3, reg=reg)

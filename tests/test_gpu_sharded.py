@@ -60,7 +60,7 @@ def _worker(rank, world, port, case_name, out_dir, local=False, shard_comm="auto
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "ragged"])
+@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "ragged", "wide_k150"])
 def test_two_ranks_one_gpu(case_name, tmp_path):
     import torch.multiprocessing as mp
     from _golden import assert_loss_rows_close, load_case, rel_fro
