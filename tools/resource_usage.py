@@ -43,7 +43,7 @@ def main():
     lines = [" ".join(cmd[1:9]) + " ...", f"{'kernel':74s} VGPR AGPR  spilled-VGPR scratch-B/lane waves/SIMD LDS-B"]
     for r_, d in zip(rows, dem):
         d = re.sub(r"^void ", "", re.sub(r"\(.*", "", d)).replace("alpine::", "")
-        if a.all or "stream_gemm" in d or "update" in d or r_.get("scratch", 0) > 0:
+        if a.all or "stream_gemm" in d or "update" in d or "wide" in d or "gram_cross" in d or r_.get("scratch", 0) > 0:
             lines.append(f"{d:74s} {r_.get('vgpr', -1):4d} {r_.get('agpr', -1):4d}  {r_.get('vspill', -1):12d} {r_.get('scratch', -1):14d} "
                          f"{r_.get('occ', -1):10d} {r_.get('lds', -1):5d}")
     text = "\n".join(lines) + "\n"
