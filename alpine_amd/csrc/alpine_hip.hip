@@ -238,8 +238,6 @@ static int geometry(const alpine_config* cfg, Geometry* g, std::string* why)
         for (int i = 0; i < cfg->n_covariates; ++i) guided += cfg->cov_components[i];
         if (guided > 128) { *why = "with more than 128 components in total the guided ones must fit in the first 128 columns (sum k_i <= 128)"; return -1; }
         if (cfg->flags & (ALPINE_FLAG_X_BF16 | ALPINE_FLAG_X_SPLIT)) { *why = "more than 128 components need the float32 storage (x3 or f32 sweeps)"; return -1; }
-        if (cfg->flags & ALPINE_FLAG_USE_ALS) { *why = "the block-coordinate branch supports at most 128 components in this build"; return -1; }
-        if (cfg->batch_capacity > 0) { *why = "mini-batches support at most 128 components in this build"; return -1; }
     }
     if (cfg->loss_type != ALPINE_LOSS_KL && cfg->loss_type != ALPINE_LOSS_FROBENIUS) { *why = "loss_type must be one of ['kl-divergence', 'frobenius']."; return -1; }
     if (!(cfg->eps >= 0) || !(cfg->alpha_W >= 0) || !(cfg->orth_W >= 0) || !(cfg->l1_ratio_W >= 0 && cfg->l1_ratio_W <= 1)) { *why = "eps/alpha_W/orth_W must be >= 0 and l1_ratio_W in [0,1]"; return -1; }
@@ -1177,9 +1175,13 @@ static int launch_sweep_wtx(alpine_ctx* c, const CellView& v)
 // Block-coordinate branch, one component group (main.py:525-588).  als_group_hht: H H^T of the view with the groups
 // before `grp` already updated (a sum over cells: in a sharded run the caller all-reduces that K x K slot of the reduce
 // block before als_group_update); als_group_update: W_grp with the block-local orthogonality term, W^TW, W^TX sweep, H_grp.
+static int launch_gram_wide(alpine_ctx* c, float* A, int64_t R, float* out);
+static int als_group_update_wide(alpine_ctx* c, const CellView& v, int grp, int k_lo, int k_hi);
+
 static int als_group_hht(alpine_ctx* c, const CellView& v, int grp)
 {
     if (grp == 0) return 0;                      // the reduce block of phase 1 already holds H H^T of the old H
+    if (c->wide) return launch_gram_wide(c, v.H, v.Np, c->red + c->red_hht);
     return launch_gram(c, v.H, v.Np, v.gramBlocksH, c->red + c->red_hht);
 }
 
@@ -1189,6 +1191,7 @@ static int als_group_update(alpine_ctx* c, const CellView& v, int grp)
     int k_lo = 0;
     for (int g = 0; g < grp; ++g) k_lo += c->cov_k[g];
     const int k_hi = grp < c->n_cov ? k_lo + c->cov_k[grp] : c->K;
+    if (c->wide) return als_group_update_wide(c, v, grp, k_lo, k_hi);
     const float* HHt = c->red + c->red_hht;
     if ((rc = launch_w_update(c, HHt, true, k_lo, k_hi, true))) return rc;
     if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
@@ -1309,62 +1312,87 @@ static int launch_wide_den(alpine_ctx* c, const float* A, int64_t rows_pad, cons
     return 0;
 }
 
-static int phase1_wide(alpine_ctx* c)
+static int phase1_wide(alpine_ctx* c, const CellView& v)
 {
     int rc;
-    const CellView& v = c->full;
     c->prof_now = c->prof && (c->prof_tick++ % c->prof_every) == 0;
     int max_k, max_ct;
     cov_maxima(c, &max_k, &max_ct);
     if (c->n_cov > 0) {
-        hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hstats_group_bytes(max_k, max_ct), c->stream, c->H, c->Y, c->B[c->bcur],
-                           c->meta, c->statPart, c->N, c->Np, WIDE_KH, (float)c->eps, c->nstat, max_k, max_ct);       // guided components: first half
+        hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hstats_group_bytes(max_k, max_ct), c->stream, v.H, v.Y, c->B[c->bcur],
+                           c->meta, c->statPart, v.N, v.Np, WIDE_KH, (float)c->eps, c->nstat, max_k, max_ct);         // guided components: first half
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(c->nstat + 1), dim3(256), 0, c->stream, c->statPart, c->kind, c->red + c->red_stats,
                        v.statBlocks, c->nstat, c->xnorm2);
     HIPCHK(c, hipGetLastError());
-    if ((rc = launch_gram_wide(c, c->H, c->Np, c->red + c->red_hht))) return rc;
+    if ((rc = launch_gram_wide(c, v.H, v.Np, c->red + c->red_hht))) return rc;
     for (int h = 0; h < 2; ++h) {
         float* pieces = c->piecesA + h * (c->piecesA_cap / 2);
         if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-        if ((rc = launch_sweep(c, v.gA, c->Xng, wide_half(c->H, c->Np, h), pieces, 0))) return rc;
+        if ((rc = launch_sweep(c, v.gA, v.Xng, wide_half(v.H, v.Np, h), pieces, 0))) return rc;
         if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
         if ((rc = launch_reduce_pieces(c, pieces, wide_half(c->red, c->Gp, h), (int)c->Gp, v.gA, WIDE_KH))) return rc;
     }
     return 0;
 }
 
-static int wide_h_apply(alpine_ctx* c, const float* num_in, bool guided)
+// H[:, k_lo..k_hi) of the view from den (already in wide_den) and the W^TX pieces (or num_in); only_cov as in launch_h_update
+static int wide_h_apply(alpine_ctx* c, const CellView& v, const float* num_in, int k_lo, int k_hi, int only_cov)
 {
-    CovMeta meta = c->meta;
-    if (!guided) meta.n_cov = 0;
-    const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)c->N + 3) / 4);
+    const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)v.N + 3) / 4);
     const float* p0 = c->piecesB;
     const float* p1 = c->piecesB + c->piecesB_cap / 2;
     if (c->loss_type == ALPINE_LOSS_KL)
-        hipLaunchKernelGGL(wide_h_apply_kernel<0>, dim3(blocks), dim3(256), 0, c->stream, c->H, c->wide_den, p0, p1, c->geomB, num_in, c->Y, c->B[c->bcur], meta,
-                           c->N, c->Np, c->K, (float)c->eps, 0, c->K, -1);
+        hipLaunchKernelGGL(wide_h_apply_kernel<0>, dim3(blocks), dim3(256), 0, c->stream, v.H, c->wide_den, p0, p1, v.gB, num_in, v.Y, c->B[c->bcur], c->meta,
+                           v.N, v.Np, c->K, (float)c->eps, k_lo, k_hi, only_cov);
     else
-        hipLaunchKernelGGL(wide_h_apply_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, c->H, c->wide_den, p0, p1, c->geomB, num_in, c->Y, c->B[c->bcur], meta,
-                           c->N, c->Np, c->K, (float)c->eps, 0, c->K, -1);
+        hipLaunchKernelGGL(wide_h_apply_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, v.H, c->wide_den, p0, p1, v.gB, num_in, v.Y, c->B[c->bcur], c->meta,
+                           v.N, v.Np, c->K, (float)c->eps, k_lo, k_hi, only_cov);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
+// W[:, k_lo..k_hi) from the reduce block (update) + the float64 partials of <XH^T, W_old> (always)
+static int wide_w_step(alpine_ctx* c, bool update, int k_lo, int k_hi, bool block_orth)
+{
+    int rc;
+    const float l1 = (float)(c->l1r * c->alpha);
+    if (update && (rc = launch_wide_den(c, c->W, c->Gp, c->red + c->red_hht, 0, k_lo, k_hi, block_orth))) return rc;
+    hipLaunchKernelGGL(wide_w_apply_kernel, dim3(c->ndot), dim3(256), 0, c->stream, c->W, c->red, c->wide_den, c->dotpart, c->G, c->Gp, c->K, l1,
+                       (float)c->eps, update ? 1 : 0, k_lo, k_hi);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// W^TW of the current W, the two W^TX sweeps over the view, den = H . 2W^TW, then the H update of [k_lo, k_hi)
+static int wide_h_step(alpine_ctx* c, const CellView& v, int k_lo, int k_hi, int only_cov)
+{
+    int rc;
+    if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
+    for (int h = 0; h < 2; ++h) {
+        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+        if ((rc = launch_sweep(c, v.gB, v.Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1))) return rc;
+        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
+    }
+    if ((rc = launch_wide_den(c, v.H, v.Np, c->WtW, 1, 0, c->K, false))) return rc;
+    return wide_h_apply(c, v, nullptr, k_lo, k_hi, only_cov);
+}
+
+static int als_group_update_wide(alpine_ctx* c, const CellView& v, int grp, int k_lo, int k_hi)
+{
+    int rc;
+    if ((rc = wide_w_step(c, true, k_lo, k_hi, true))) return rc;
+    return wide_h_step(c, v, k_lo, k_hi, grp);
+}
+
 static int grow_losses(alpine_ctx* c);
 
-// [loss row of the factors that produced the reduce block], W update, B updates, W^TW, W^TX sweeps, H update: the unfused sequence of
-// phase2 with every K-templated kernel replaced by its blocked form
-static int phase2_wide(alpine_ctx* c, bool update, bool finalize)
+// pending loss row (from the factors that produced the reduce block) and all B updates: what precedes the H side in both branches
+static int wide_loss_and_b(alpine_ctx* c, bool update, bool finalize)
 {
     int rc;
     float* HHt = c->red + c->red_hht;
-    const float l1 = (float)(c->l1r * c->alpha);
-    if (update && (rc = launch_wide_den(c, c->W, c->Gp, HHt, 0, 0, c->K, false))) return rc;
-    hipLaunchKernelGGL(wide_w_apply_kernel, dim3(c->ndot), dim3(256), 0, c->stream, c->W, c->red, c->wide_den, c->dotpart, c->G, c->Gp, c->K, l1,
-                       (float)c->eps, update ? 1 : 0, 0, c->K);
-    HIPCHK(c, hipGetLastError());
     if (finalize) {
         if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, c->stream, c->dotpart, c->ndot, c->WtW, HHt, c->red + c->red_stats, c->meta,
@@ -1372,22 +1400,29 @@ static int phase2_wide(alpine_ctx* c, bool update, bool finalize)
         HIPCHK(c, hipGetLastError());
         c->loss_rows++;
     }
-    if (!update) return 0;
-    if (c->n_cov > 0) {
+    if (update && c->n_cov > 0) {
         hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
                            wide_block(HHt, 0, 0), c->meta, WIDE_KH, (float)c->eps);                                    // guided components: block (0, 0)
         HIPCHK(c, hipGetLastError());
         c->bcur ^= 1;
     }
-    if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
-    for (int h = 0; h < 2; ++h) {
-        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-        if ((rc = launch_sweep(c, c->geomB, c->Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1))) return rc;
-        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    }
-    if ((rc = launch_wide_den(c, c->H, c->Np, c->WtW, 1, 0, c->K, false))) return rc;
-    if ((rc = wide_h_apply(c, nullptr, true))) return rc;
+    return 0;
+}
+
+// [loss row of the factors that produced the reduce block], W update, B updates, W^TW, W^TX sweeps, H update: the unfused sequence of
+// phase2 with every K-templated kernel replaced by its blocked form
+static int phase2_wide(alpine_ctx* c, const CellView& v, bool update, bool finalize)
+{
+    int rc;
     c->tail_valid = false;
+    if ((rc = wide_w_step(c, update && !c->use_als, 0, c->K, false))) return rc;
+    if ((rc = wide_loss_and_b(c, update, finalize))) return rc;
+    if (!update) return 0;
+    if (!c->use_als) return wide_h_step(c, v, 0, c->K, -1);
+    for (int grp = 0; grp <= c->n_cov; ++grp) {          // block-coordinate branch, main.py:525-588
+        if ((rc = als_group_hht(c, v, grp))) return rc;
+        if ((rc = als_group_update(c, v, grp))) return rc;
+    }
     return 0;
 }
 
@@ -1405,7 +1440,7 @@ static int transform_wide(alpine_ctx* c, int n_iter)
     HIPCHK(c, hipGetLastError());
     for (int it = 0; it < n_iter; ++it) {
         if ((rc = launch_wide_den(c, c->H, c->Np, c->WtW, 1, 0, c->K, false))) return rc;
-        if ((rc = wide_h_apply(c, c->wide_num, false))) return rc;
+        if ((rc = wide_h_apply(c, c->full, c->wide_num, 0, c->K, c->n_cov))) return rc;      // only_cov = n_cov: no guided terms
     }
     return 0;
 }
@@ -1415,7 +1450,7 @@ extern "C" int alpine_iter_begin(alpine_ctx* c)
     int rc = ready(c);
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
-    return c->wide ? phase1_wide(c) : phase1(c, c->full);
+    return c->wide ? phase1_wide(c, c->full) : phase1(c, c->full);
 }
 
 extern "C" int alpine_iter_end(alpine_ctx* c, int update)
@@ -1423,7 +1458,7 @@ extern "C" int alpine_iter_end(alpine_ctx* c, int update)
     int rc = ready(c);
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
-    rc = c->wide ? phase2_wide(c, update != 0, c->pending_loss && c->loss_enabled)
+    rc = c->wide ? phase2_wide(c, c->full, update != 0, c->pending_loss && c->loss_enabled)
                  : phase2(c, c->full, update != 0, c->pending_loss && c->loss_enabled);
     if (rc) return rc;
     c->pending_loss = update != 0;
@@ -1441,6 +1476,12 @@ extern "C" int alpine_als_begin(alpine_ctx* c)
     if (c->transform_only || !c->use_als) return fail(c, ALPINE_ERR_STATE, "alpine_als_begin needs a ctx created with ALPINE_FLAG_USE_ALS");
     const float* HHt = c->red + c->red_hht;
     const bool finalize = c->pending_loss && c->loss_enabled;
+    if (c->wide) {
+        if ((rc = wide_w_step(c, false, 0, c->K, false))) return rc;
+        if ((rc = wide_loss_and_b(c, true, finalize))) return rc;
+        c->pending_loss = true;
+        return 0;
+    }
     if ((rc = launch_w_update(c, HHt, false, 0, c->K, false))) return rc;        // dot partials of <XH^T, W_old> only
     if (finalize) {
         if (c->loss_rows == c->loss_cap && (rc = grow_losses(c))) return rc;
@@ -1603,7 +1644,13 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
     const int nb = c->n_cu * 8;
     // gather the view: rows of the cells x genes copy, rows of H, columns of Y; then the genes x cells copy by transpose
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Xng, c->Gp, c->idx_dev, (int)n, (int)Bp, c->Xb_ng, c->Gp, (int)c->Gp);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->H, (int64_t)KP, c->idx_dev, (int)n, (int)Bp, c->Hb, (int64_t)KP, KP);
+    if (c->wide) {
+        for (int h = 0; h < 2; ++h)      // blocked factors: each half is a [rows][128] array of its own (the view's halves are Bp rows apart)
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, wide_half(c->H, c->Np, h), (int64_t)WIDE_KH, c->idx_dev, (int)n, (int)Bp,
+                               wide_half(c->Hb, Bp, h), (int64_t)WIDE_KH, WIDE_KH);
+    } else {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->H, (int64_t)KP, c->idx_dev, (int)n, (int)Bp, c->Hb, (int64_t)KP, KP);
+    }
     if (c->nYrows > 0)
         hipLaunchKernelGGL(gather_cols_kernel, dim3(nb), dim3(256), 0, c->stream, c->Y, c->Np, c->idx_dev, (int)n, (int)Bp, c->Yb, Bp, c->nYrows);
     {
@@ -1625,7 +1672,7 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
         if (v.statBlocks > c->statPart_cap || (Bp + 4 * rpw - 1) / (4 * rpw) > c->gramPart_cap)
             return fail(c, ALPINE_ERR_STATE, "internal: batch view needs more partial blocks than were allocated");
     }
-    if ((rc = phase1(c, v))) return rc;
+    if ((rc = c->wide ? phase1_wide(c, v) : phase1(c, v))) return rc;
     c->batch_open = true;
     return 0;
 }
@@ -1640,6 +1687,11 @@ extern "C" int alpine_batch_end(alpine_ctx* c)
         // none of the batch's cells live here: only the replicated updates (W from the reduced sums, every B_i)
         if (c->use_als) return fail(c, ALPINE_ERR_UNSUPPORTED, "empty local batches are not supported with ALPINE_FLAG_USE_ALS");
         const float* HHt = c->red + c->red_hht;
+        c->pending_loss = false;
+        if (c->wide) {
+            if ((rc = wide_w_step(c, true, 0, c->K, false))) return rc;
+            return wide_loss_and_b(c, true, false);
+        }
         if ((rc = launch_w_update(c, HHt, true, 0, c->K, false))) return rc;
         if (c->n_cov > 0) {
             hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
@@ -1647,12 +1699,17 @@ extern "C" int alpine_batch_end(alpine_ctx* c)
             HIPCHK(c, hipGetLastError());
             c->bcur ^= 1;
         }
-        c->pending_loss = false;
         return 0;
     }
-    if ((rc = phase2(c, c->batch_view, true, false))) return rc;
+    if ((rc = c->wide ? phase2_wide(c, c->batch_view, true, false) : phase2(c, c->batch_view, true, false))) return rc;
     const int nb = c->n_cu * 8;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Hb, (int64_t)c->KP, c->idx_dev, (int)c->batch_n, c->H, (int64_t)c->KP, c->KP);
+    if (c->wide) {
+        for (int h = 0; h < 2; ++h)
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb), dim3(256), 0, c->stream, wide_half(c->Hb, c->batch_view.Np, h), (int64_t)WIDE_KH, c->idx_dev,
+                               (int)c->batch_n, wide_half(c->H, c->Np, h), (int64_t)WIDE_KH, WIDE_KH);
+    } else {
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Hb, (int64_t)c->KP, c->idx_dev, (int)c->batch_n, c->H, (int64_t)c->KP, c->KP);
+    }
     HIPCHK(c, hipGetLastError());
     c->pending_loss = false;
     return 0;
@@ -1676,7 +1733,10 @@ extern "C" int alpine_epoch_loss_begin(alpine_ctx* c)
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
     if (c->batch_open) return fail(c, ALPINE_ERR_STATE, "alpine_epoch_loss_begin inside an open batch");
-    if (c->wide) return fail(c, ALPINE_ERR_UNSUPPORTED, "mini-batch epochs support at most 128 components in this build");
+    if (c->wide) {
+        if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
+        return phase1_wide(c, c->full);
+    }
     if ((rc = launch_gram(c, c->W, c->Gp, c->gramBlocksW, c->WtW))) return rc;
     return phase1(c, c->full);
 }
@@ -1686,7 +1746,7 @@ extern "C" int alpine_epoch_loss_end(alpine_ctx* c)
     int rc = ready(c);
     if (rc) return rc;
     if (c->transform_only) return fail(c, ALPINE_ERR_STATE, "ctx was created with ALPINE_FLAG_TRANSFORM_ONLY");
-    if ((rc = phase2(c, c->full, false, true))) return rc;
+    if ((rc = c->wide ? phase2_wide(c, c->full, false, true) : phase2(c, c->full, false, true))) return rc;
     c->pending_loss = false;
     return 0;
 }

@@ -306,7 +306,7 @@ class ALPINE:
     # limits of libalpine_hip.so that the reference does not have ("Deviations"): checked here so that the
     # user gets a Python-side message before any device work, instead of a late native status
     MAX_TOTAL_COMPONENTS = 256
-    MAX_FAST_COMPONENTS = 128              # up to here: the fused MFMA path; above: the blocked two-half path (full batch, MU, float32 storage)
+    MAX_FAST_COMPONENTS = 128              # up to here: the fused MFMA path; above: the blocked two-half path (float32 storage)
     MAX_COVARIATE_COMPONENTS = 64           # per covariate; their sum may reach the total
     MAX_COVARIATES = 16
 
@@ -321,19 +321,15 @@ class ALPINE:
             raise NotImplementedError(f"n_components + sum(n_covariate_components) = {self.total_components} > "
                                       f"{self.MAX_TOTAL_COMPONENTS} is not supported by the MI355X build")
         if self.total_components > self.MAX_FAST_COMPONENTS:
-            # 128 < K <= 256 runs on the blocked two-half path (kernels_wide.hpp): full-batch multiplicative updates only
+            # 128 < K <= 256 runs on the blocked two-half path (kernels_wide.hpp)
             if sum(ks) > self.MAX_FAST_COMPONENTS:
                 raise NotImplementedError(f"with more than {self.MAX_FAST_COMPONENTS} components in total, sum(n_covariate_components) must be <= "
                                           f"{self.MAX_FAST_COMPONENTS} in the MI355X build (got {sum(ks)})")
-            if self.use_als:
-                raise NotImplementedError(f"use_als=True supports at most {self.MAX_FAST_COMPONENTS} components in total in the MI355X build")
             if self.x_dtype not in ("x3", "f32", "auto"):
                 raise NotImplementedError(f"more than {self.MAX_FAST_COMPONENTS} components need float32 storage: x_dtype='x3', 'f32' or 'auto'")
         if self.sampling_method not in ("random", "weighted"):
             raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
         if self._uses_batches(n_sample):
-            if self.total_components > self.MAX_FAST_COMPONENTS:
-                raise NotImplementedError(f"mini-batches / weighted sampling support at most {self.MAX_FAST_COMPONENTS} components in total in the MI355X build")
             if self.use_als and self.shard_cells:
                 raise NotImplementedError("use_als=True with mini-batches is single-device (sharded: full batch only)")
             if self.x_dtype not in ("f32", "x3", "auto"):

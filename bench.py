@@ -559,7 +559,8 @@ def main():
         mf = dtype == "f32"
         launches = m["n_a"] + m["n_b"]
         avg_ms = (m["ms_a"] + m["ms_b"]) / max(1, launches)
-        flops_per_launch = 2.0 * G * n_loc * K                    # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
+        passes = 2 if K > 128 else 1                               # 128 < K <= 256: each sweep is two launches, one per component half
+        flops_per_launch = 2.0 * G * n_loc * K / passes           # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
         bytes_per_launch = (4.0 if dtype in ("f32", "x3") else 2.0) * G * n_loc   # X read once per sweep (counts: ONE bf16 plane in split mode)
         ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -590,7 +591,8 @@ def main():
             "avg_ms_xht": m["ms_a"] / max(1, m["n_a"]), "avg_ms_wtx": m["ms_b"] / max(1, m["n_b"]),
             "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
             "tflops": ach_tf, "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS,
-            "sweeps_share_of_step": ((m["ms_a"] / max(1, m["n_a"]) + m["ms_b"] / max(1, m["n_b"])) / (1e3 * m["dt"] / args.steps)) if m["dt"] > 0 else 0.0,
+            "sweep_launches_per_step": 2 * passes,
+            "sweeps_share_of_step": (passes * (m["ms_a"] / max(1, m["n_a"]) + m["ms_b"] / max(1, m["n_b"])) / (1e3 * m["dt"] / args.steps)) if m["dt"] > 0 else 0.0,
             "x3_wide": int(info.x3_wide), "x_multi_plane_fraction": float(info.x_multi_plane_fraction),
             "accumulation_span_rows": [int(info.span_rows_a), int(info.span_rows_b)],
         }

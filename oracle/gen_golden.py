@@ -198,6 +198,22 @@ CASES = [
     dict(name="wide_k200_fro", n_cells=130, n_genes=90, seed=37, T=5,
          covariates=[("c1", ["x", "y"], 0.0)],
          params=dict(n_components=190, n_covariate_components=[10], lam=[4.0], loss_type="frobenius")),
+    # ... the block-coordinate branch and mini-batches on that path
+    dict(name="als_wide_k150", n_cells=120, n_genes=100, seed=38, T=4,
+         covariates=[("c1", ["x", "y", "z"], 0.05), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=138, n_covariate_components=[7, 5], lam=[1e3, 2e2], use_als=True, orth_W=0.05, alpha_W=0.2, l1_ratio_W=0.5)),
+    dict(name="als_wide_k160_fro", n_cells=110, n_genes=96, seed=39, T=4,
+         covariates=[("c1", ["x", "y"], 0.0)],
+         params=dict(n_components=150, n_covariate_components=[10], lam=[3.0], use_als=True, loss_type="frobenius")),
+    dict(name="mb_wide_k150", n_cells=150, n_genes=90, seed=40, T=6, fit_kwargs=dict(batch_size=48),
+         covariates=[("c1", ["x", "y", "z"], 0.0), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=141, n_covariate_components=[5, 4], lam=[1e3, 5e2], orth_W=0.05)),
+    dict(name="mb_weighted_wide_k140", n_cells=160, n_genes=80, seed=41, T=5, fit_kwargs=dict(batch_size=50, sampling_method="weighted"),
+         covariates=[("c1", ["x", "y", "z"], 0.1)],
+         params=dict(n_components=134, n_covariate_components=[6], lam=[1e2], alpha_W=0.3, l1_ratio_W=0.5, loss_type="frobenius")),
+    dict(name="als_mb_wide_k140", n_cells=140, n_genes=80, seed=42, T=4, fit_kwargs=dict(batch_size=64),
+         covariates=[("c1", ["x", "y"], 0.0)],
+         params=dict(n_components=132, n_covariate_components=[8], lam=[1e2], use_als=True, orth_W=0.02)),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,

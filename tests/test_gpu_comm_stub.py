@@ -74,7 +74,7 @@ def test_native_loop_two_ranks_full_batch(case_name, local, tmp_path):
     assert rel_fro(H, np.concatenate(single.matrices["Hs"], axis=0)) < 2e-5
 
 
-@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True)])
+@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True), ("als_wide_k160_fro", False)])
 def test_native_loop_two_ranks_block_coordinate(case_name, local, tmp_path):
     """use_als: alpine_iter exchanges the K x K H H^T slot after every component group, in C."""
     r = _spawn(case_name, tmp_path, local)
@@ -83,7 +83,7 @@ def test_native_loop_two_ranks_block_coordinate(case_name, local, tmp_path):
     _check_against_golden(c, r, local)
 
 
-@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", True), ("weighted_skew", False)])
+@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", True), ("weighted_skew", False), ("mb_wide_k150", True)])
 def test_native_loop_two_ranks_minibatch(case_name, local, tmp_path):
     """Mini-batches: alpine_batch_step (gather, phase 1, exchange, phase 2, scatter) and alpine_epoch_loss with the
     communicator attached, including batches of which a rank holds no cell (weighted_skew: most draws fall into rank 0's

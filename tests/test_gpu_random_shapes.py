@@ -79,8 +79,22 @@ def test_random_shape_two_steps_vs_oracle(seed):
 def test_random_shape_als_and_minibatch_vs_oracle(seed):
     """Block-coordinate branch (use_als) and mini-batch steps on random shapes against the oracle's op-for-op restatement
     (als_step_faithful / mu_step_faithful on explicit index batches)."""
+    _als_and_minibatch_vs_oracle(seed)
+
+
+@pytest.mark.parametrize("seed,Ku", [(120, 129), (121, 140), (122, 200), (123, 250), (124, 131), (125, 170)])
+def test_wide_als_and_minibatch_vs_oracle(seed, Ku):
+    """The same on the blocked two-half path (128 < K <= 256): gathered views of the blocked H, the group loop with block-local
+    orthogonality over both halves, epoch loss rows."""
+    _als_and_minibatch_vs_oracle(seed, Ku=Ku)
+
+
+def _als_and_minibatch_vs_oracle(seed, Ku=None):
     from alpine_amd import _native as nat
     p, X, Ys, _, _ = _case(seed)
+    if Ku is not None:
+        p.n_components = Ku - sum(p.n_covariate_components) if seed % 3 else Ku      # K = Ku exactly, or Ku unguided + the guided ones
+        p.n_components = min(p.n_components, 256 - sum(p.n_covariate_components))
     if not p.n_covariate_components:            # the reference's ALS / sampler code needs at least one covariate
         p.n_covariate_components, p.lam = [2], [10.0]
         Ys = [np.eye(2, dtype=np.float32)[np.random.default_rng(seed).integers(0, 2, size=X.shape[0])]]

@@ -110,7 +110,7 @@ def test_two_ranks_local_input(case_name, tmp_path):
 
 
 @pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", False), ("mb_weighted", True), ("full_weighted", True),
-                                             ("weighted_skew", False)])
+                                             ("weighted_skew", False), ("mb_wide_k150", False), ("mb_weighted_wide_k140", True)])
 def test_two_ranks_minibatch(case_name, local, tmp_path):
     """Mini-batch / weighted sampling sharded over two ranks: both draw the same global index stream, each takes the
     batch's cells that fall into its block (sometimes none), the reduce block is all-reduced between batch_begin and
@@ -131,7 +131,7 @@ def test_two_ranks_minibatch(case_name, local, tmp_path):
     assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
 
 
-@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True)])
+@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True), ("als_wide_k150", False)])
 def test_two_ranks_use_als(case_name, local, tmp_path):
     """Block-coordinate branch sharded over two ranks: one extra all-reduce of the K x K H H^T slot per component group."""
     import torch.multiprocessing as mp

@@ -216,11 +216,7 @@ def test_build_limits_are_reported_from_python_before_any_device_work():
         ALPINE(n_components=3, n_covariate_components=[65, 3], lam=[1.0, 1.0]).fit(a, covariate_keys=["c", "d"], max_iter=1)
     with pytest.raises(NotImplementedError, match="> 256"):
         ALPINE(n_components=255, n_covariate_components=[2], lam=[1.0]).fit(a, covariate_keys=["c"], max_iter=1)
-    # 128 < K <= 256: the blocked two-half path -- full-batch multiplicative updates, float32 storage, guided components in the first half
-    with pytest.raises(NotImplementedError, match="use_als=True supports at most 128"):
-        ALPINE(n_components=140, n_covariate_components=[2], lam=[1.0], use_als=True).fit(a, covariate_keys=["c"], max_iter=1)
-    with pytest.raises(NotImplementedError, match="mini-batches / weighted sampling support at most 128"):
-        ALPINE(n_components=140, n_covariate_components=[2], lam=[1.0]).fit(a, covariate_keys=["c"], max_iter=1, batch_size=8)
+    # 128 < K <= 256: the blocked two-half path -- float32 storage, guided components in the first half
     with pytest.raises(NotImplementedError, match="must be <= 128"):
         ALPINE(n_components=100, n_covariate_components=[64, 64, 10], lam=[1.0, 1.0, 1.0]).fit(a, covariate_keys=["c", "d", "c"], max_iter=1)
     with pytest.raises(NotImplementedError, match="need float32 storage"):
