@@ -11,7 +11,8 @@
 //   * the updates split into  den = A . M  (wide_den_kernel: the MFMA core of w_update_mfma_kernel, the 128 x 128 block (i, o)
 //     of M staged through LDS for each pair of halves) and an elementwise apply (wide_w_apply_kernel, wide_h_apply_kernel with
 //     the guided terms of main.py:636-650; all guided components must sit in the first half: sum k_i <= 128).
-// No fused tails, no MFMA form of the guided terms: a wide iteration is ~25 launches and reads X four times instead of twice.
+// The block-coordinate branch (k_lo, k_hi, block_orth, only_cov) and mini-batch views (rows_pad = the view's padded cells) use the same
+// kernels.  No fused tails, no MFMA form of the guided terms: a wide iteration is ~25 launches and reads X four times instead of twice.
 // It exists so that K up to 256 RUNS with the reference's results, not to be fast.
 #pragma once
 #include "kernels.hpp"

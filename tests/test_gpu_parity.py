@@ -309,10 +309,10 @@ def test_errors_are_loud():
     eng.close()
     with pytest.raises(nat.AlpineNativeError):
         nat.NativeShard(n_genes=64, n_cells=96, n_components=255, cov_components=[2], cov_levels=[2], lam=[1.0])       # K = 257 > 256
-    with pytest.raises(nat.AlpineNativeError, match="block-coordinate branch supports at most 128"):
-        nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0], use_als=True)
-    with pytest.raises(nat.AlpineNativeError, match="mini-batches support at most 128"):
-        nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0], batch_capacity=32)
+    with pytest.raises(nat.AlpineNativeError, match="need the float32 storage"):
+        nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0], x_dtype="bf16")
+    with pytest.raises(nat.AlpineNativeError, match="must fit in the first 128 columns"):
+        nat.NativeShard(n_genes=64, n_cells=96, n_components=50, cov_components=[60, 50, 40], cov_levels=[2, 2, 2], lam=[1.0, 1.0, 1.0])
 
 
 TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74", "k0_split", "guided_wide", "wide_k150"]
