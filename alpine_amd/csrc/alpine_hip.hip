@@ -46,7 +46,8 @@ struct alpine_ctx {
     CovMeta meta{};
     int nstat = 0, nB = 0, nYrows = 0;
     int device = 0, n_cu = 256;
-    size_t lds_max = 160 * 1024;      // LDS a workgroup may use (hipDeviceAttributeMaxSharedMemoryPerBlock)
+    size_t lds_max = 160 * 1024;      // LDS a workgroup may use (hipDeviceAttributeMaxSharedMemoryPerBlock); ALPINE_HIP_LDS_LIMIT lowers it for the H update's optional parts
+    size_t lds_dev = 160 * 1024;      // ... the device's own figure (every other kernel's fixed LDS need is checked against this one)
     // stream
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -306,6 +307,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     {
         int lds = 0;
         if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) == hipSuccess && (size_t)lds > c->lds_max) c->lds_max = (size_t)lds;   // gfx950: 160 KiB per CU
+        c->lds_dev = c->lds_max;
         if (const char* e = std::getenv("ALPINE_HIP_LDS_LIMIT")) { const long v = std::atol(e); if (v > 0 && (size_t)v < c->lds_max) c->lds_max = (size_t)v; }   // tests: exercise the fall-backs
     }
     c->unfused_mid = getenv_is("ALPINE_HIP_UNFUSED_MID", '1');
@@ -1078,6 +1080,7 @@ static int launch_w_update(alpine_ctx* c, const float* HHt, bool update, int k_l
     } else {
         // 32 genes per wave: ceil(G/128) blocks; the remaining dotpart entries stay at their initial zero
         const size_t bytes = sizeof(float) * (KP * KP + 4 * 32 * (KP + 4));          // M + the waves' row-major tiles
+        if (bytes > c->lds_dev) return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the W update needs %zu bytes of LDS, the device has %zu", bytes, c->lds_dev);
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_mfma_kernel<KT_>, dim3((c->G + 127) / 128), dim3(256), bytes, c->stream, c->W, c->red,
                                                HHt, c->dotpart, c->G, c->K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0, k_lo, k_hi,
                                                block_orth ? 1 : 0, gram_part));
@@ -1307,6 +1310,7 @@ static int launch_wide_den(alpine_ctx* c, const float* A, int64_t rows_pad, cons
     a.orth = (float)c->orth; a.l2 = (float)((1.0 - c->l1r) * c->alpha);
     a.k_lo = k_lo; a.k_hi = k_hi; a.block_orth = block_orth ? 1 : 0;
     const size_t lds = sizeof(float) * (WIDE_KH * WIDE_KH + 4 * 32 * (WIDE_KH + 4));
+    if (lds > c->lds_dev) return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the blocked update needs %zu bytes of LDS, the device has %zu", lds, c->lds_dev);
     hipLaunchKernelGGL(wide_den_kernel, dim3((unsigned)(rows_pad / 128)), dim3(256), lds, c->stream, A, G, c->wide_den, a);
     HIPCHK(c, hipGetLastError());
     return 0;

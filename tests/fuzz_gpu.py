@@ -175,7 +175,7 @@ def run_case(seed):
         out.append(f"{mode}:{eW:.1e}/{eH:.1e}")
     # now and then: block-coordinate branch / mini-batches against the op-for-op oracle on the same data
     extra = ""
-    if p.n_covariate_components and N <= 6000 and rng.random() < 0.5 and p.total_components <= 128:
+    if p.n_covariate_components and N <= 6000 and rng.random() < 0.5:
         use_als = bool(rng.integers(0, 2))
         p.use_als = use_als
         bs = int(rng.integers(max(2, N // 5), N + 1))
