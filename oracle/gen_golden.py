@@ -79,6 +79,11 @@ def make_case_inputs(case: dict):
     obs = {}
     for key, levels, nan_frac in case["covariates"]:
         obs[key] = _labels(rng, n, levels, nan_frac)
+    # degenerate inputs: genes never expressed / empty cells (exact zeros through every product and both updates)
+    for gidx in case.get("zero_genes", []):
+        X[:, gidx] = 0.0
+    for cidx in case.get("zero_cells", []):
+        X[cidx, :] = 0.0
     if case.get("skew_first"):
         # the first covariate becomes: its first level on the first `skew_first` cells, its second level everywhere else (a
         # rare, heavily weighted joint label that lives in the FIRST shard of a cell-sharded run)
@@ -214,6 +219,23 @@ CASES = [
     dict(name="als_mb_wide_k140", n_cells=140, n_genes=80, seed=42, T=4, fit_kwargs=dict(batch_size=64),
          covariates=[("c1", ["x", "y"], 0.0)],
          params=dict(n_components=132, n_covariate_components=[8], lam=[1e2], use_als=True, orth_W=0.02)),
+    # degenerate inputs the reference accepts: genes that are zero in every cell, cells that are zero in every gene, a covariate
+    # with ONE level, labels that are mostly missing, a matrix smaller than any tile
+    dict(name="zeros_kl", transform_iters=5, n_cells=100, n_genes=70, seed=43, T=12, zero_genes=[0, 3, 40, 69], zero_cells=[0, 5, 77, 99],
+         covariates=[("c1", ["x", "y"], 0.0)],
+         params=dict(n_components=5, n_covariate_components=[2], lam=[1e3])),
+    dict(name="zeros_fro_reg", n_cells=100, n_genes=70, seed=44, T=12, zero_genes=[1, 2, 33], zero_cells=[10, 11, 98],
+         covariates=[("c1", ["x", "y", "z"], 0.1)],
+         params=dict(n_components=6, n_covariate_components=[3], lam=[5.0], loss_type="frobenius", orth_W=0.05, alpha_W=0.3, l1_ratio_W=0.5)),
+    dict(name="one_level_sparse_labels", n_cells=90, n_genes=60, seed=45, T=10,
+         covariates=[("only", ["a"], 0.0), ("rare", ["p", "q", "r"], 0.9)],
+         params=dict(n_components=4, n_covariate_components=[2, 2], lam=[1e2, 1e3])),
+    dict(name="tiny", transform_iters=4, n_cells=9, n_genes=5, seed=46, T=8,
+         covariates=[("c1", ["x", "y"], 0.0)],
+         params=dict(n_components=2, n_covariate_components=[1], lam=[10.0])),
+    dict(name="tiny_als", n_cells=7, n_genes=11, seed=47, T=6,
+         covariates=[("c1", ["x", "y"], 0.0)],
+         params=dict(n_components=3, n_covariate_components=[2], lam=[10.0], use_als=True, orth_W=0.1)),
     # BASELINE.json configs[0]: the reference's own CPU-runnable case.  X is regenerated from
     # the seed by the tests (40 MB is not a fixture); only outputs + an input checksum are stored.
     dict(name="cfg1", n_cells=5000, n_genes=2000, seed=0, T=50, store_X=False,

@@ -315,7 +315,7 @@ def test_errors_are_loud():
         nat.NativeShard(n_genes=64, n_cells=96, n_components=50, cov_components=[60, 50, 40], cov_levels=[2, 2, 2], lam=[1.0, 1.0, 1.0])
 
 
-TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74", "k0_split", "guided_wide", "wide_k150"]
+TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74", "k0_split", "guided_wide", "wide_k150", "zeros_kl", "tiny"]
 
 
 @pytest.mark.parametrize("name", TRANSFORM_CASES)
