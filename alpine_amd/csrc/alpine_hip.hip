@@ -669,7 +669,7 @@ static int sum_f64_partials(alpine_ctx* c, int n, double* out)
     return 0;
 }
 
-static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which);
+static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which, int active16 = 0);
 
 extern "C" int alpine_finalize_X(alpine_ctx* c)
 {
@@ -917,7 +917,9 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
     return 0;
 }
 
-static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which)
+// active16 > 0 (wide models, second component half): only that many 16-component tiles of the panel hold real components; the x3w form
+// leaves the others unmultiplied (zero accumulators, same pieces layout), the other forms ignore the hint
+static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which, int active16)
 {
     // the division about to be launched must fit the pieces buffer it writes (sized in create_impl for every division this ctx
     // may use): an error here instead of an out-of-bounds write on the device
@@ -932,8 +934,15 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
         int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
         if (c->ablate_flush) gx.panel_fixed = 2;
         else if (c->ablate_panel) gx.panel_fixed = 1;
+        if (c->x3_wide && !c->x3_ablate && c->wide && active16 > 0 && active16 < 7) {
+#define X3W_PART(M_) case M_: hipLaunchKernelGGL((stream_gemm_x3w_kernel<4, 1, M_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); break
+            switch (active16) { X3W_PART(1); X3W_PART(2); X3W_PART(3); X3W_PART(4); X3W_PART(5); default: X3W_PART(6); }
+#undef X3W_PART
+            HIPCHK(c, hipGetLastError());
+            return 0;
+        }
         if (c->x3_wide && !c->x3_ablate) {
-            const bool pad_tile = !c->wide && c->K <= c->KP - 16;          // the last 16-component tile is all padding: not multiplied
+            const bool pad_tile = (!c->wide && c->K <= c->KP - 16) || (c->wide && active16 == 7);          // the last 16-component tile is all padding: not multiplied
 #define X3W_LAUNCH(KT_, NH_) do { \
                 if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); \
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); } while (0)
@@ -1286,6 +1295,8 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
 // ---------------------------------------------------------------------------------- wide models (128 < K <= 256, kernels_wide.hpp)
 static float* wide_half(float* base, int64_t rows_pad, int h) { return base + (int64_t)h * rows_pad * WIDE_KH; }
 static float* wide_block(float* base, int a, int b) { return base + (int64_t)(a * 2 + b) * WIDE_KH * WIDE_KH; }
+// 16-component tiles of half h that hold real components (0 = all of them)
+static int wide_active16(const alpine_ctx* c, int h) { return h == 0 ? 0 : (c->K - WIDE_KH + 15) / 16; }
 
 // out (blocked [2][2][128][128]) = A^T A for a blocked A [2][R][128]
 static int launch_gram_wide(alpine_ctx* c, float* A, int64_t R, float* out)
@@ -1334,7 +1345,7 @@ static int phase1_wide(alpine_ctx* c, const CellView& v)
     for (int h = 0; h < 2; ++h) {
         float* pieces = c->piecesA + h * (c->piecesA_cap / 2);
         if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-        if ((rc = launch_sweep(c, v.gA, v.Xng, wide_half(v.H, v.Np, h), pieces, 0))) return rc;
+        if ((rc = launch_sweep(c, v.gA, v.Xng, wide_half(v.H, v.Np, h), pieces, 0, wide_active16(c, h)))) return rc;
         if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
         if ((rc = launch_reduce_pieces(c, pieces, wide_half(c->red, c->Gp, h), (int)c->Gp, v.gA, WIDE_KH))) return rc;
     }
@@ -1376,7 +1387,7 @@ static int wide_h_step(alpine_ctx* c, const CellView& v, int k_lo, int k_hi, int
     if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
     for (int h = 0; h < 2; ++h) {
         if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-        if ((rc = launch_sweep(c, v.gB, v.Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1))) return rc;
+        if ((rc = launch_sweep(c, v.gB, v.Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1, wide_active16(c, h)))) return rc;
         if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
     }
     if ((rc = launch_wide_den(c, v.H, v.Np, c->WtW, 1, 0, c->K, false))) return rc;
@@ -1436,7 +1447,7 @@ static int transform_wide(alpine_ctx* c, int n_iter)
     if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
     for (int h = 0; h < 2; ++h) {
         if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-        if ((rc = launch_sweep(c, c->geomB, c->Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1))) return rc;
+        if ((rc = launch_sweep(c, c->geomB, c->Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1, wide_active16(c, h)))) return rc;
         if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
     }
     const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)c->N + 3) / 4);
@@ -1902,26 +1913,28 @@ extern "C" int alpine_debug_run_graph(alpine_ctx* c, int n_pairs)
     int rc = ready(c);
     if (rc) return rc;
     if (c->comm || c->use_als || c->transform_only || n_pairs < 1) return fail(c, ALPINE_ERR_UNSUPPORTED, "single-shard MU loop only");
-    const bool prof = c->prof;
+    // whatever happens below, the ctx gets its profiling / loss switches back and the graph objects are released
+    struct Restore {
+        alpine_ctx* c; bool prof;
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        ~Restore() {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            c->loss_enabled = true; c->prof = prof; c->pending_loss = true;
+        }
+    } keep{c, c->prof};
     c->prof = false;
     c->loss_enabled = false;
     for (int it = 0; it < 2; ++it) if ((rc = alpine_iter(c, 1))) return rc;          // reach the steady state (fused tails valid)
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     for (int it = 0; it < 2 && !rc; ++it) rc = alpine_iter(c, 1);
-    hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    const hipError_t e = hipStreamEndCapture(c->stream, &keep.graph);               // always ends the capture, also after a failed launch
+    if (rc) return rc;
     HIPCHK(c, e);
-    HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    for (int p = 0; p < n_pairs; ++p) HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    HIPCHK(c, hipGraphInstantiate(&keep.exec, keep.graph, nullptr, nullptr, 0));
+    for (int p = 0; p < n_pairs; ++p) HIPCHK(c, hipGraphLaunch(keep.exec, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
-    c->loss_enabled = true;
-    c->prof = prof;
-    c->pending_loss = true;
     return 0;
 }
 

@@ -358,7 +358,7 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
 {
     sg_report_xcc(xcc_out);
     static_assert(KT * NH <= 4, "256 accumulator registers per lane");
-    static_assert(M16A == 2 * KT || M16A == 2 * KT - 1, "at most one padding tile");
+    static_assert(M16A >= 1 && M16A <= 2 * KT, "active 16-component tiles");   // < 2 KT - 1 only for the second half of a wide model (K = 150: 2 of 8)
     constexpr int KP = 32 * KT, M16 = 2 * KT;
     constexpr int WAVE_F = 128 * NH, BLOCK_F = 4 * WAVE_F, NCG = 2 * NH;       // 64-column groups per wave
     constexpr int NT = 256;

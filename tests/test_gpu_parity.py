@@ -3,6 +3,8 @@
  (b) the CPU oracle on the same seeded inputs.
 Tolerances are the stated ones: rel-Frobenius 1e-5 after one step,
 1e-4 after T <= 50 iterations; loss rows 5e-5 relative."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -903,8 +905,11 @@ def test_placement_probe_and_graph_replay_are_result_neutral():
     c = load_case("mid_counts")
     eng = make_engine(c, x_dtype="x3")
     info = eng.info()
-    assert 0 <= info.xcc_of_workgroup0 < 8 and abs(info.xcd_bias_per_mille) in (0, 40)
-    assert (info.xcc_of_workgroup0 & 1) == (1 if info.xcd_bias_per_mille < 0 else 0) or info.xcd_bias_per_mille == 0
+    if "ALPINE_HIP_XCD_BIAS" in os.environ:              # (the knob matrix: a forced bias switches the probe off)
+        assert info.xcc_of_workgroup0 == -1 and info.xcd_bias_per_mille == int(os.environ["ALPINE_HIP_XCD_BIAS"])
+    else:
+        assert 0 <= info.xcc_of_workgroup0 < 8 and abs(info.xcd_bias_per_mille) in (0, 40)
+        assert (info.xcc_of_workgroup0 & 1) == (1 if info.xcd_bias_per_mille < 0 else 0) or info.xcd_bias_per_mille == 0
     assert info.span_rows_a <= 16384 and info.span_rows_b <= 16384
     eng.run(2 + 2 * 3, with_loss=False)                 # what alpine_debug_run_graph(3) runs: 2 eager iterations, then 3 replays of 2
     W1, H1, B1 = eng.get_factors()

@@ -277,3 +277,15 @@ def test_wide_models_vs_oracle(Ku, ks, levels, loss, reg):
     """128 < K <= 256: the blocked two-half path (kernels_wide.hpp; every update as den = A.M on the MFMA + an elementwise apply, the
     sweeps once per half) against the oracle's fused iteration, ragged G and N, x3 and f32 sweeps, loss rows included."""
     _fit_vs_oracle(300 + Ku, G=203, N=517, Ku=Ku, ks=ks, levels=levels, loss=loss, iters=3, reg=reg)
+
+
+@pytest.mark.parametrize("G,N,Ku,ks,levels,loss", [
+    (70001, 1030, 9, [3], [2], "kl-divergence"),          # more genes than a 16-bit index, ragged in both axes
+    (140003, 700, 33, [], [], "frobenius"),               # 137 gene tiles of 1024, fewer cells than one tile
+    (131072, 257, 60, [2, 2], [2, 3], "kl-divergence"),   # 2^17 genes exactly, one cell past two 128-cell blocks
+    (40, 150001, 5, [1], [2], "frobenius"),               # the other extreme: one partial gene tile, 147 cell tiles, spans capped at 16 384 rows
+])
+def test_extreme_aspect_ratios_vs_oracle(G, N, Ku, ks, levels, loss):
+    """Matrices far from the benchmark's aspect ratio (the fuzz campaign keeps G <= 3200): very tall (many gene tiles, few cells) and very
+    flat; 2 iterations against the oracle's fused iteration in both sweep modes."""
+    _fit_vs_oracle(900 + G % 97, G=G, N=N, Ku=Ku, ks=ks, levels=levels, loss=loss, iters=2)
