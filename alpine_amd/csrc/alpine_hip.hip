@@ -1305,11 +1305,16 @@ static int launch_gram_wide(alpine_ctx* c, float* A, int64_t R, float* out)
     const int blocks = (int)((R + 4 * rpw - 1) / (4 * rpw));
     if (blocks > c->gramPart_cap) return fail(c, ALPINE_ERR_STATE, "internal: Gram partial buffer too small");
     const int n = WIDE_KH * WIDE_KH;
+    const int tiles[2] = {WIDE_KT, (c->K - WIDE_KH + 31) / 32};           // 32-component tiles with real components, per half
     for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b) {
-            hipLaunchKernelGGL(gram_cross_kernel<WIDE_KT>, dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw);
+        for (int b = a; b < 2; ++b) {
+            hipLaunchKernelGGL(gram_cross_kernel<WIDE_KT>, dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw,
+                               tiles[a], tiles[b]);
             hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, wide_block(out, a, b), n, blocks);
         }
+    // block (1, 0) = block (0, 1) transposed (the same products summed in the same order)
+    hipLaunchKernelGGL(transpose_kernel, dim3(WIDE_KH / 32, WIDE_KH / 32), dim3(256), 0, c->stream, wide_block(out, 0, 1), (int64_t)WIDE_KH, wide_block(out, 1, 0),
+                       (int64_t)WIDE_KH, WIDE_KH, WIDE_KH);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -23,9 +23,11 @@ constexpr int WIDE_KH = 128;      // components per half
 constexpr int WIDE_KT = 4;        // 32-column tiles per half
 
 // part[blk][k][k'] = sum_{r in rows of block blk} A[r][k] * A2[r][k']   (A, A2: R x KH row-major; A2 == A gives the plain Gram)
+// ta / tb: 32-component tiles of A / A2 that hold real components (the others are zero columns: neither loaded nor multiplied, their
+// part of the output stays zero)
 template <int KT>
 __global__ __launch_bounds__(256, 1)
-void gram_cross_kernel(const float* __restrict__ A, const float* __restrict__ A2, float* __restrict__ part, int R, int rows_per_wave)
+void gram_cross_kernel(const float* __restrict__ A, const float* __restrict__ A2, float* __restrict__ part, int R, int rows_per_wave, int ta, int tb)
 {
     constexpr int KP = 32 * KT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -48,8 +50,8 @@ void gram_cross_kernel(const float* __restrict__ A, const float* __restrict__ A2
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int m = 0; m < KT; ++m) {
-                v[p][m] = A[(int64_t)(r + 2 * p + h) * KP + 32 * m + c];
-                v2[p][m] = A2[(int64_t)(r + 2 * p + h) * KP + 32 * m + c];
+                v[p][m] = m < ta ? A[(int64_t)(r + 2 * p + h) * KP + 32 * m + c] : 0.f;            // (grid-uniform predicates)
+                v2[p][m] = m < tb ? A2[(int64_t)(r + 2 * p + h) * KP + 32 * m + c] : 0.f;
             }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -57,7 +59,8 @@ void gram_cross_kernel(const float* __restrict__ A, const float* __restrict__ A2
             for (int a = 0; a < KT; ++a)
 #pragma unroll
                 for (int b = 0; b < KT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][a], v2[p][b], acc[a][b], 0, 0, 0);
+                    if (a < ta && b < tb)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][a], v2[p][b], acc[a][b], 0, 0, 0);
     }
     // the block's 4 waves are summed in wave order through LDS -> one partial per block (fixed order)
     __shared__ float gl[KP * KP];
@@ -114,23 +117,34 @@ void wide_den_kernel(const float* __restrict__ A, const float* __restrict__ G, f
         for (int i = 0; i < 2; ++i) {
             __syncthreads();                                                 // the previous block of M has been consumed
             const float* Gb = G + (int64_t)(i * 2 + o) * KP * KP;
-            for (int idx = tid; idx < KP * KP; idx += 256) {
-                const int kp = i * KP + idx / KP, k = o * KP + idx % KP;      // global component indices (contraction, output)
-                float v = 0.f;
-                if (kp < a.K && k < a.K) {
-                    v = 2.f * Gb[idx];
-                    if (a.mode == 0) {
-                        const bool coupled = !a.block_orth || (kp >= a.k_lo && kp < a.k_hi);
-                        v += (kp == k) ? a.l2 : (coupled ? a.orth : 0.f);
+#pragma unroll 4
+            for (int idx4 = tid; idx4 < KP * KP / 4; idx4 += 256) {             // float4 per thread and trip: 16 trips, four loads in flight
+                const int kp = i * KP + idx4 / (KP / 4), k0 = o * KP + 4 * (idx4 % (KP / 4));     // global component indices (contraction, output)
+                const f32x4 gsrc = reinterpret_cast<const f32x4*>(Gb)[idx4];
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + e;
+                    float x = 0.f;
+                    if (kp < a.K && k < a.K) {
+                        x = 2.f * gsrc[e];
+                        if (a.mode == 0) {
+                            const bool coupled = !a.block_orth || (kp >= a.k_lo && kp < a.k_hi);
+                            x += (kp == k) ? a.l2 : (coupled ? a.orth : 0.f);
+                        }
                     }
+                    v[e] = x;
                 }
-                Ml[idx] = v;
+                reinterpret_cast<f32x4*>(Ml)[idx4] = v;
             }
             __syncthreads();
             f32x4 wreg[KT][4];
             tile_load_cd<KT>(A + ((int64_t)i * a.rows_pad + r0) * KP, tr, lane, wreg);
+            // 32-component tiles that are all padding (K = 150: three of the second half's four) are skipped on both sides: their rows of
+            // M are zero (contraction side) and their columns of den are never read (output side; they stay zero)
 #pragma unroll
-            for (int m = 0; m < KT; ++m)
+            for (int m = 0; m < KT; ++m) {
+                if (i * KP + 32 * m >= a.K) continue;                                            // block-uniform
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -138,8 +152,10 @@ void wide_den_kernel(const float* __restrict__ A, const float* __restrict__ G, f
                         const float* mrow = Ml + (32 * m + 8 * q + 4 * h + e) * KP + c;      // A operand [i = k][kk = k'] = M[k'][k]
 #pragma unroll
                         for (int mo = 0; mo < KT; ++mo)
-                            acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], wreg[m][q][e], acc[mo], 0, 0, 0);
+                            if (o * KP + 32 * mo < a.K)                                          // block-uniform
+                                acc[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(mrow[32 * mo], wreg[m][q][e], acc[mo], 0, 0, 0);
                     }
+            }
         }
         f32x4 outv[KT][4];
 #pragma unroll
