@@ -1700,14 +1700,20 @@ void w_update_mfma_kernel(float* __restrict__ W, const float* __restrict__ XHt, 
     const int c = lane & 31, h = lane >> 5;
     float* tr = trall + wave * TRSZ;
     if (do_update) {
-        for (int idx = tid; idx < KP * KP; idx += 256) {
-            const int kp = idx / KP, k = idx % KP;
-            float v = 0.f;
-            if (kp < K && k < K) {
-                const bool coupled = !block_orth || (kp >= k_lo && kp < k_hi);
-                v = 2.f * HHt[idx] + (kp == k ? l2 : (coupled ? orth : 0.f));
+        // float4 per thread and trip, four loads in flight (the scalar form of this loop was one L2 round trip per trip: 16 trips at
+        // K <= 64, 64 at K <= 128, on the critical chain of every block)
+#pragma unroll 4
+        for (int idx4 = tid; idx4 < KP * KP / 4; idx4 += 256) {
+            const int kp = idx4 / (KP / 4), k0 = 4 * (idx4 % (KP / 4));
+            const f32x4 src = reinterpret_cast<const f32x4*>(HHt)[idx4];
+            const bool coupled = !block_orth || (kp >= k_lo && kp < k_hi);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + e;
+                v[e] = (kp < K && k < K) ? 2.f * src[e] + (kp == k ? l2 : (coupled ? orth : 0.f)) : 0.f;
             }
-            Ml[idx] = v;
+            reinterpret_cast<f32x4*>(Ml)[idx4] = v;
         }
         __syncthreads();
     }
@@ -1789,7 +1795,8 @@ void h_iterate_mfma_kernel(float* __restrict__ H, const float* __restrict__ piec
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    for (int idx = tid; idx < KP * KP; idx += 256) M2l[idx] = 2.f * WtW[idx];
+    for (int idx = tid; idx < KP * KP / 4; idx += 256)
+        reinterpret_cast<f32x4*>(M2l)[idx] = 2.f * reinterpret_cast<const f32x4*>(WtW)[idx];
     __syncthreads();
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
     if (n0 >= N) return;

@@ -19,7 +19,7 @@ HU_PHASES = ["fills (Y, 2W^TW, guided tables) + barrier", "H issue + pieces + H 
              "tile store", "barrier + H H^T partial", "covariate statistics"]
 
 
-def engine(cells, x_scale, env):
+def engine(cells, x_scale, env, workload="cfg3"):
     os.environ["ALPINE_HIP_LIBRARY"] = LIB
     for kv in env:
         k, v = kv.split("=", 1)
@@ -30,11 +30,12 @@ def engine(cells, x_scale, env):
     from alpine_amd import _native
     from alpine_amd.datasets import synth_counts_device_chunks
     from alpine_amd.model import draw_initial_factors
-    wl = dict(bench.WORKLOADS["cfg3"])
+    wl = dict(bench.WORKLOADS[workload])
     G, N, ku, kcov = wl["genes"], cells, wl["ku"], wl["kcov"]
     dev = torch.device("cuda", 0)
-    W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], [2, 2])
-    eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=[2, 2], lam=[1e3, 1e3],
+    lev = [2] * len(kcov)
+    W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], lev)
+    eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=lev, lam=[1e3] * len(kcov),
                               orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype="x3")
     for off, chunk in synth_counts_device_chunks(N, G, rank=ku, seed=0, device=dev, chunk_cells=8192):
         if x_scale != 1.0:
@@ -43,7 +44,7 @@ def engine(cells, x_scale, env):
         eng.upload_X_device(chunk.data_ptr(), chunk.stride(0), chunk.shape[0], _native.X_CELLS_BY_GENES, off)
         eng.synchronize()
     eng.finalize_X()
-    for i in range(2):
+    for i in range(len(kcov)):
         eng.upload_Y(i, bench.labels_onehot(N, seed=1 + i))
     eng.set_factors(W0, H0, B0)
     return eng, _native
@@ -54,7 +55,7 @@ def pc(v):
 
 
 def sweep(a):
-    eng, nat = engine(a.cells, a.x_scale, a.env)
+    eng, nat = engine(a.cells, a.x_scale, a.env, a.workload)
     eng.run(20, with_loss=True)
     eng.synchronize()
     info = eng.info()
@@ -104,7 +105,7 @@ def sweep(a):
 
 
 def hupdate(a):
-    eng, nat = engine(a.cells, 1.0, a.env)
+    eng, nat = engine(a.cells, 1.0, a.env, a.workload)
     eng.run(10, with_loss=True)
     eng.synchronize()
     lib = nat.load()
@@ -128,6 +129,7 @@ if __name__ == "__main__":
     ap.add_argument("--cells", type=int, default=25000)
     ap.add_argument("--x-scale", type=float, default=1.0)
     ap.add_argument("--env", action="append", default=[])
+    ap.add_argument("--workload", default="cfg3", help="model of this bench.py workload (cfg4: K = 105)")
     a = ap.parse_args()
     if not os.path.exists(LIB):
         sys.exit("build the stamped library first: python alpine_amd/build.py --stamps")
