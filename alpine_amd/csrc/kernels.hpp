@@ -414,7 +414,7 @@ __host__ __device__ __forceinline__ int64_t sg_piece_offset_inner(const SweepGeo
 
 // out[f][k] = sum over the pieces of f's tile (ascending workgroup, float64 accumulation), f < rows.
 // The piece loop is latency-bound when written one load per trip (a tile has ~13 pieces on the fixed stream-K grid,
-// whatever the shard size): loads are issued four pieces at a time, the adds stay in ascending order.
+// whatever the shard size): loads are issued nine, then eight pieces at a time, the adds stay in ascending order.
 __device__ __forceinline__ void reduce_pieces_block(const float* __restrict__ pieces, float* __restrict__ out, int rows, int KP, const SweepGeom& g,
                                                     int block, int nblocks)
 {
@@ -426,19 +426,19 @@ __device__ __forceinline__ void reduce_pieces_block(const float* __restrict__ pi
         int w_lo, w_hi;
         sg_tile_pieces(g, ft, w_lo, w_hi);
         const int64_t in_piece = (int64_t)fl * KP + 4 * k4;
+        // the first piece together with the next eight (predicated), then eight at a time: a tile's ~13 pieces are two round trips
+        // instead of four; the adds stay in ascending workgroup order (same sums as the sequential form)
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset(g, w_lo, ft, KP) + in_piece);
-        double a0 = v0[0], a1 = v0[1], a2 = v0[2], a3 = v0[3];
-        int w = w_lo + 1;
-        for (; w + 3 <= w_hi; w += 4) {
-            f32x4 v[4];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int w = w_lo + 1; w == w_lo + 1 || w <= w_hi; w += 8) {
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset_inner(g, w + u, KP) + in_piece);
+            for (int u = 0; u < 8; ++u)
+                v[u] = (w + u <= w_hi) ? *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset_inner(g, w + u, KP) + in_piece) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (w == w_lo + 1) { a0 = v0[0]; a1 = v0[1]; a2 = v0[2]; a3 = v0[3]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; a2 += v[u][2]; a3 += v[u][3]; }
-        }
-        for (; w <= w_hi; ++w) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(pieces + sg_piece_offset_inner(g, w, KP) + in_piece);
-            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            for (int u = 0; u < 8; ++u)
+                if (w + u <= w_hi) { a0 += v[u][0]; a1 += v[u][1]; a2 += v[u][2]; a3 += v[u][3]; }
         }
         f32x4 o = {(float)a0, (float)a1, (float)a2, (float)a3};
         *reinterpret_cast<f32x4*>(out + (int64_t)f * KP + 4 * k4) = o;
@@ -792,9 +792,16 @@ __device__ __forceinline__ void reduce_slabs_block(const float* __restrict__ in,
 #pragma unroll
             for (int u = 0; u < 8; ++u) { a[0] += v[u][0]; a[1] += v[u][1]; a[2] += v[u][2]; a[3] += v[u][3]; }
         }
-        for (; sidx < nslab; sidx += 64) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)sidx * n);
-            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        // the remainder (fewer than 8 slabs per lane: e.g. the 157 partial blocks of W^T W) as ONE batch of predicated loads instead of
+        // one dependent round trip per slab; the additions keep their order, so the sums are bit-identical to the sequential form
+        {
+            f32x4 v[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                v[u] = (sidx + 64 * u < nslab) ? *reinterpret_cast<const f32x4*>(p + (int64_t)(sidx + 64 * u) * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (sidx + 64 * u < nslab) { a[0] += v[u][0]; a[1] += v[u][1]; a[2] += v[u][2]; a[3] += v[u][3]; }
         }
     }
 #pragma unroll
@@ -1489,9 +1496,17 @@ void h_update_mfma_kernel(float* __restrict__ H, const float* __restrict__ piece
     {
         // Y of this block's 128 cells: one load phase up front instead of a dependent global load per (covariate, class)
         const int64_t cell0 = (int64_t)blockIdx.x * HS_CELLS;
-        for (int idx = tid; idx < ybuf_alloc * HS_CELLS; idx += 256) {
-            const int row = idx >> 7, t = idx & (HS_CELLS - 1);
-            ybuf[idx] = (row < tail.ybuf_rows && cell0 + t < N) ? Y[(int64_t)row * Np + cell0 + t] : 0.f;
+        const int ytotal = ybuf_alloc * HS_CELLS;
+        for (int idx0 = tid; idx0 < ytotal; idx0 += 4 * 256) {               // four loads in flight per thread (run-time trip count: not unrolled otherwise)
+            float yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + 256 * u, row = idx >> 7, t = idx & (HS_CELLS - 1);
+                yv[u] = (idx < ytotal && row < tail.ybuf_rows && cell0 + t < N) ? Y[(int64_t)row * Np + cell0 + t] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (idx0 + 256 * u < ytotal) ybuf[idx0 + 256 * u] = yv[u];
         }
     }
     for (int idx = tid; idx < KP * KP / 4; idx += 256)
@@ -1890,9 +1905,31 @@ __device__ __forceinline__ void loss_finalize_block(const double* __restrict__ d
 {
     __shared__ double red[256];
     const int t = threadIdx.x;
+    // batches of four independent loads per thread (as scalar loops these were one L2 round trip per trip -- 10 + 16 trips at K <= 64,
+    // 10 + 64 at K <= 128 -- and this block is the longest of its launch)
     double a = 0.0;
-    for (int i = t; i < ndot; i += 256) a -= 2.0 * dotpart[i];
-    for (int i = t; i < KP * KP; i += 256) a += (double)WtW[i] * (double)HHt[i];
+    int i = t;
+    for (; i + 3 * 256 < ndot; i += 4 * 256) {
+        const double d0 = dotpart[i], d1 = dotpart[i + 256], d2 = dotpart[i + 512], d3 = dotpart[i + 768];
+        a -= 2.0 * d0; a -= 2.0 * d1; a -= 2.0 * d2; a -= 2.0 * d3;
+    }
+    for (; i < ndot; i += 256) a -= 2.0 * dotpart[i];
+    const int n4 = KP * KP / 4;                                   // KP is a multiple of 32
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(WtW);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(HHt);
+    for (i = t; i < n4; i += 4 * 256) {
+        f32x4 w[4], hh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = i + 256 * u < n4;
+            w[u] = in ? w4[i + 256 * u] : f32x4{0.f, 0.f, 0.f, 0.f};
+            hh[u] = in ? h4[i + 256 * u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += (double)w[u][e] * (double)hh[u][e];
+    }
     red[t] = a;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
