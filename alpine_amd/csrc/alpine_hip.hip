@@ -37,7 +37,8 @@ struct alpine_ctx {
     int G = 0, N = 0, K = 0, KP = 0, KT = 0, n_cov = 0;
     // wide model (128 < K <= 256, kernels_wide.hpp): KP = 256, KT = 4 = tiles per HALF, factors in the blocked layout [2][rows][128]
     bool wide = false;
-    float *wide_den = nullptr, *wide_num = nullptr;     // [2][max(Gp, Np)][128] product A.M of the updates; [2][Np][128] transform numerator
+    float *wide_den = nullptr, *wide_num = nullptr;     // [2][wide_den_rows][128] product A.M of the updates; [2][Np][128] transform numerator
+    int64_t wide_den_rows = 0;
     int64_t Gp = 0, Np = 0;
     std::vector<int> cov_k, cov_lev;
     std::vector<double> lam;
@@ -423,7 +424,10 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     ALLOC(c, c->W, float, Gp * KP);
     ALLOC(c, c->H, float, Np * KP);
     if (c->wide) {
-        ALLOC(c, c->wide_den, float, std::max(Gp, Np) * KP);
+        // den = A . M for the rows of W, of H, or of a mini-batch view of H -- which may hold MORE cells than the shard (draws with
+        // replacement, or a global batch whose cells all fall into this rank's block): sized for the largest of the three
+        c->wide_den_rows = std::max(std::max(Gp, Np), round_up(std::max<int64_t>(c->N, cfg->batch_capacity), 128));
+        ALLOC(c, c->wide_den, float, c->wide_den_rows * KP);
         ALLOC(c, c->wide_num, float, Np * KP);
     }
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
@@ -1325,6 +1329,7 @@ static int launch_wide_den(alpine_ctx* c, const float* A, int64_t rows_pad, cons
     a.rows_pad = (int)rows_pad; a.K = c->K; a.mode = mode;
     a.orth = (float)c->orth; a.l2 = (float)((1.0 - c->l1r) * c->alpha);
     a.k_lo = k_lo; a.k_hi = k_hi; a.block_orth = block_orth ? 1 : 0;
+    if (rows_pad > c->wide_den_rows) return fail(c, ALPINE_ERR_STATE, "internal: the blocked update has %lld rows, its buffer holds %lld", (long long)rows_pad, (long long)c->wide_den_rows);
     const size_t lds = sizeof(float) * (WIDE_KH * WIDE_KH + 4 * 32 * (WIDE_KH + 4));
     if (lds > c->lds_dev) return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the blocked update needs %zu bytes of LDS, the device has %zu", lds, c->lds_dev);
     hipLaunchKernelGGL(wide_den_kernel, dim3((unsigned)(rows_pad / 128)), dim3(256), lds, c->stream, A, G, c->wide_den, a);

@@ -289,3 +289,40 @@ def test_extreme_aspect_ratios_vs_oracle(G, N, Ku, ks, levels, loss):
     """Matrices far from the benchmark's aspect ratio (the fuzz campaign keeps G <= 3200): very tall (many gene tiles, few cells) and very
     flat; 2 iterations against the oracle's fused iteration in both sweep modes."""
     _fit_vs_oracle(900 + G % 97, G=G, N=N, Ku=Ku, ks=ks, levels=levels, loss=loss, iters=2)
+
+
+@pytest.mark.parametrize("Ku", [20, 150])
+def test_minibatch_view_larger_than_the_shard(Ku):
+    """A mini-batch drawn with replacement may hold MORE cells than the ctx (a sharded rank whose block receives most of a global batch;
+    batch_capacity > n_cells): every buffer a view touches must be sized for the view, not for the shard.  Found by
+    tests/fuzz_sharded_gpu.py (seed 30429, round 3): the blocked path's den buffer was sized for max(Gp, Np) rows -- a device fault at
+    K = 239 with a 8 120-cell batch capacity on a 4 096-cell shard."""
+    from alpine_amd import _native as nat
+    rng = np.random.default_rng(77 + Ku)
+    G, N, cap = 90, 300, 1000
+    X = rng.gamma(0.5, 2.0, size=(N, G)).astype(np.float32)
+    Y = np.eye(3, dtype=np.float32)[rng.integers(0, 3, size=N)]
+    p = orc.OracleParams(n_components=Ku, n_covariate_components=[4], lam=[30.0], orth_W=0.05, loss_type="kl-divergence", random_state=5)
+    s = orc.init_factors(p, np.ascontiguousarray(X.T), [Y])
+    W0, H0, B0 = s.W.numpy().copy(), s.H.numpy().copy(), [b.numpy().copy() for b in s.Bs]
+    batches = [rng.integers(0, N, size=n) for n in (cap, 650, 129, cap)]
+    with torch.no_grad():
+        for idx in batches:
+            orc.mu_step_faithful(p, s, torch.tensor(idx, dtype=torch.long))
+        s.losses.append(orc.loss_row(p, s))
+    for mode in ("x3", "f32"):
+        eng = nat.NativeShard(n_genes=G, n_cells=N, n_components=Ku, cov_components=[4], cov_levels=[3], lam=p.lam, orth_W=p.orth_W,
+                              eps=p.eps, loss_type=p.loss_type, batch_capacity=cap, x_dtype=mode)
+        eng.upload_X_host(X)
+        eng.finalize_X()
+        eng.upload_Y(0, np.ascontiguousarray(Y.T))
+        eng.set_factors(W0, H0, B0)
+        for idx in batches:
+            eng.batch_step(idx)
+        eng.epoch_loss()
+        W, H, Bs = eng.get_factors()
+        losses = eng.losses()
+        eng.close()
+        assert rel_fro(W, s.W.numpy()) < 5e-5 and rel_fro(H, s.H.numpy()) < 5e-5, mode
+        assert rel_fro(Bs[0], s.Bs[0].numpy()) < 1e-4, mode
+        np.testing.assert_allclose(losses[:, :2], np.array(s.losses)[:, :2], rtol=1e-4, err_msg=mode)
