@@ -1312,8 +1312,12 @@ static int launch_gram_wide(alpine_ctx* c, float* A, int64_t R, float* out)
     const int tiles[2] = {WIDE_KT, (c->K - WIDE_KH + 31) / 32};           // 32-component tiles with real components, per half
     for (int a = 0; a < 2; ++a)
         for (int b = a; b < 2; ++b) {
-            hipLaunchKernelGGL(gram_cross_kernel<WIDE_KT>, dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw,
-                               tiles[a], tiles[b]);
+            if (tiles[a] == WIDE_KT && tiles[b] == WIDE_KT)
+                hipLaunchKernelGGL((gram_cross_kernel<WIDE_KT, true>), dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw,
+                                   WIDE_KT, WIDE_KT);
+            else
+                hipLaunchKernelGGL((gram_cross_kernel<WIDE_KT, false>), dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw,
+                                   tiles[a], tiles[b]);
             hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, wide_block(out, a, b), n, blocks);
         }
     // block (1, 0) = block (0, 1) transposed (the same products summed in the same order)

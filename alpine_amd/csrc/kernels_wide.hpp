@@ -25,10 +25,13 @@ constexpr int WIDE_KT = 4;        // 32-column tiles per half
 // part[blk][k][k'] = sum_{r in rows of block blk} A[r][k] * A2[r][k']   (A, A2: R x KH row-major; A2 == A gives the plain Gram)
 // ta / tb: 32-component tiles of A / A2 that hold real components (the others are zero columns: neither loaded nor multiplied, their
 // part of the output stays zero)
-template <int KT>
+// FULL: ta = tb = KT known at compile time (the (0, 0) block of every model, every block at K = 256): no predicates -- the predicated form
+// costs 32 spilled registers, which the blocks with padding tiles pay for with their fewer MFMAs
+template <int KT, bool FULL>
 __global__ __launch_bounds__(256, 1)
 void gram_cross_kernel(const float* __restrict__ A, const float* __restrict__ A2, float* __restrict__ part, int R, int rows_per_wave, int ta, int tb)
 {
+    if (FULL) { ta = KT; tb = KT; }
     constexpr int KP = 32 * KT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -44,22 +47,22 @@ void gram_cross_kernel(const float* __restrict__ A, const float* __restrict__ A2
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    for (int r = r0; r < r1; r += 8) {
-        float v[4][KT], v2[4][KT];
+    for (int r = r0; r < r1; r += 4) {                 // (four rows per trip: with eight the predicated form below spilled 32 registers)
+        float v[2][KT], v2[2][KT];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int m = 0; m < KT; ++m) {
-                v[p][m] = m < ta ? A[(int64_t)(r + 2 * p + h) * KP + 32 * m + c] : 0.f;            // (grid-uniform predicates)
-                v2[p][m] = m < tb ? A2[(int64_t)(r + 2 * p + h) * KP + 32 * m + c] : 0.f;
+                v[p][m] = (FULL || m < ta) ? A[(int64_t)(r + 2 * p + h) * KP + 32 * m + c] : 0.f;            // (grid-uniform predicates)
+                v2[p][m] = (FULL || m < tb) ? A2[(int64_t)(r + 2 * p + h) * KP + 32 * m + c] : 0.f;
             }
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int a = 0; a < KT; ++a)
 #pragma unroll
                 for (int b = 0; b < KT; ++b)
-                    if (a < ta && b < tb)
+                    if (FULL || (a < ta && b < tb))
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][a], v2[p][b], acc[a][b], 0, 0, 0);
     }
     // the block's 4 waves are summed in wave order through LDS -> one partial per block (fixed order)
