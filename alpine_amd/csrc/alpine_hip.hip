@@ -47,6 +47,8 @@ struct alpine_ctx {
     CovMeta meta{};
     int nstat = 0, nB = 0, nYrows = 0;
     int device = 0, n_cu = 256;
+    struct GuardRec { void* user; size_t bytes; const char* name; };
+    std::vector<GuardRec> guards;     // ALPINE_HIP_GUARD=1 (diagnostics): every device buffer sits between two pattern-filled zones, checked when it is freed
     size_t lds_max = 160 * 1024;      // LDS a workgroup may use (hipDeviceAttributeMaxSharedMemoryPerBlock); ALPINE_HIP_LDS_LIMIT lowers it for the H update's optional parts
     size_t lds_dev = 160 * 1024;      // ... the device's own figure (every other kernel's fixed LDS need is checked against this one)
     // stream
@@ -183,11 +185,18 @@ static int fail(alpine_ctx* c, int code, const char* fmt, ...)
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static bool getenv_is(const char* name, char v) { const char* e = std::getenv(name); return e && e[0] == v; }
 
-static int dev_alloc(alpine_ctx* c, void** p, size_t bytes, bool zero = true)
+// Diagnostics, ALPINE_HIP_GUARD=1: a device-side write past either end of a buffer does not fault when the neighbouring addresses are
+// mapped (another buffer, or host memory the runtime keeps pinned) -- it corrupts silently.  In guard mode every buffer is allocated with
+// a 4 KiB zone of 0xA5 on both sides; dev_free / alpine_destroy compare the zones and abort with the buffer's name when one was touched.
+static const bool g_guard = std::getenv("ALPINE_HIP_GUARD") != nullptr && std::getenv("ALPINE_HIP_GUARD")[0] == '1';
+constexpr size_t GUARD_BYTES = 4096;
+
+static int dev_alloc(alpine_ctx* c, void** p, size_t bytes, bool zero = true, const char* name = "")
 {
     if (bytes == 0) bytes = 16;
+    const size_t want = g_guard ? ((bytes + 255) & ~(size_t)255) + 2 * GUARD_BYTES : bytes;
     {
-        const hipError_t e = hipMalloc(p, bytes);
+        const hipError_t e = hipMalloc(p, want);
         if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
             (void)hipGetLastError();                      // the failed allocation must not surface again at the next check
             size_t free_b = 0, total_b = 0;
@@ -201,11 +210,43 @@ static int dev_alloc(alpine_ctx* c, void** p, size_t bytes, bool zero = true)
         HIPCHK(c, e);
     }
     c->bytes += bytes;
+    if (g_guard) {
+        char* base = static_cast<char*>(*p);
+        HIPCHK(c, hipMemsetAsync(base, 0xA5, want, c->stream));
+        *p = base + GUARD_BYTES;
+        c->guards.push_back({*p, bytes, name});
+    }
     if (zero) HIPCHK(c, hipMemsetAsync(*p, 0, bytes, c->stream));
     return 0;
 }
+
+// guard mode: compare the two zones of the buffer `user` (abort with its name if one was written); returns the pointer hipFree wants
+static void* guard_check(alpine_ctx* c, void* user, bool forget)
+{
+    if (!g_guard || !user) return user;
+    for (size_t i = 0; i < c->guards.size(); ++i) {
+        if (c->guards[i].user != user) continue;
+        const alpine_ctx::GuardRec r = c->guards[i];
+        char* base = static_cast<char*>(user) - GUARD_BYTES;
+        const size_t tail = ((r.bytes + 255) & ~(size_t)255) - r.bytes + GUARD_BYTES;
+        std::vector<unsigned char> lo(GUARD_BYTES), hi(tail);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(lo.data(), base, GUARD_BYTES, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hi.data(), static_cast<char*>(user) + r.bytes, tail, hipMemcpyDeviceToHost);
+        for (size_t k = 0; k < GUARD_BYTES; ++k)
+            if (lo[k] != 0xA5) { std::fprintf(stderr, "alpine guard: buffer %s (%zu bytes) was written %zu bytes BEFORE its start\n", r.name, r.bytes, GUARD_BYTES - k); std::abort(); }
+        for (size_t k = 0; k < tail; ++k)
+            if (hi[k] != 0xA5) { std::fprintf(stderr, "alpine guard: buffer %s (%zu bytes) was written %zu bytes PAST its end\n", r.name, r.bytes, k); std::abort(); }
+        if (forget) c->guards.erase(c->guards.begin() + (long)i);
+        return base;
+    }
+    return user;
+}
+
+static hipError_t dev_free(alpine_ctx* c, void* user) { return hipFree(guard_check(c, user, true)); }
+
 #define ALLOC(c, ptr, T, count) \
-    do { int rc_ = dev_alloc((c), reinterpret_cast<void**>(&(ptr)), sizeof(T) * (size_t)(count)); if (rc_) return rc_; } while (0)
+    do { int rc_ = dev_alloc((c), reinterpret_cast<void**>(&(ptr)), sizeof(T) * (size_t)(count), true, #ptr); if (rc_) return rc_; } while (0)
 
 // ---------------------------------------------------------------------------------- geometry
 struct Geometry {
@@ -516,7 +557,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
                     c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->rowtab, c->xcc_dev, c->wide_den, c->wide_num, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : ptrs) if (p) (void)dev_free(c, p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -664,9 +705,13 @@ extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout
 
 static int sum_f64_partials(alpine_ctx* c, int n, double* out)
 {
+    // device -> pageable host memory: the stream is drained first and the copy is the BLOCKING call.  (hipMemcpyAsync into a pageable
+    // buffer followed by hipStreamSynchronize is not a guarantee on this platform that the bytes have landed when the synchronise
+    // returns: the last hop, staging buffer -> user buffer, may run afterwards -- into a std::vector that has already been freed.
+    // tests/fuzz_model_gpu.py: stray 8-byte writes into freed heap chunks, about one process crash per 400 compute_loss calls.)
     std::vector<double> h(n);
-    HIPCHK(c, hipMemcpyAsync(h.data(), c->f64part, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h.data(), c->f64part, sizeof(double) * n, hipMemcpyDeviceToHost));
     double s = 0;
     for (double v : h) s += v;
     *out = s;
@@ -695,8 +740,8 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         if (h[0]) return fail(c, ALPINE_ERR_UNSUPPORTED, "X is not exactly representable as the sum of two bf16 planes (more than 16 significant bits): use the float32 layout");
         c->npx = h[1] ? 2 : 1;        // small integer counts: the second plane is all zero and is never read
         if (c->npx == 1) {            // ... so give its memory back
-            if (c->Xgn16b) { HIPCHK(c, hipFree(c->Xgn16b)); c->Xgn16b = nullptr; c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
-            if (c->Xng16b) { HIPCHK(c, hipFree(c->Xng16b)); c->Xng16b = nullptr; if (!c->transform_only) c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
+            if (c->Xgn16b) { HIPCHK(c, dev_free(c, c->Xgn16b)); c->Xgn16b = nullptr; c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
+            if (c->Xng16b) { HIPCHK(c, dev_free(c, c->Xng16b)); c->Xng16b = nullptr; if (!c->transform_only) c->bytes -= sizeof(unsigned short) * (size_t)(c->Gp * c->Np); }
             c->x_plane2_dropped = true;                      // further uploads would write plane 2 into freed memory: refused (check_x_args)
         }
     }
@@ -740,8 +785,8 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         c->probe_placement = false;
         if (rc) return rc;
         int h = -1;
-        HIPCHK(c, hipMemcpyAsync(&h, c->xcc_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(&h, c->xcc_dev, sizeof(int), hipMemcpyDeviceToHost));      // blocking (see sum_f64_partials)
         c->xcc_of_wg0 = h;
         const int bias = h < 0 ? 0 : ((h & 1) ? -XCD_BIAS_MAG : XCD_BIAS_MAG);      // workgroup 0 on an odd XCC: the even workgroups are the slow ones
         if (bias != c->xcd_bias_pm) {
@@ -832,8 +877,8 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
             hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->W + (int64_t)h * c->Gp * kph, kph,
                                c->stage + h * kph, (int64_t)K, (int64_t)c->G, kh);
         }
-        HIPCHK(c, hipMemcpyAsync(W, c->stage, sizeof(float) * (size_t)c->G * K, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(W, c->stage, sizeof(float) * (size_t)c->G * K, hipMemcpyDeviceToHost));      // blocking copies into caller memory (see sum_f64_partials)
     }
     if (H) {
         for (int h = 0; h < halves; ++h) {
@@ -842,12 +887,12 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
             hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->H + (int64_t)h * c->Np * kph, (int64_t)kph,
                                c->stage + (int64_t)h * kph * c->N, (int64_t)c->N, c->N, kh);
         }
-        HIPCHK(c, hipMemcpy2DAsync(H, sizeof(float) * ldH, c->stage, sizeof(float) * c->N, sizeof(float) * c->N, (size_t)K, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy2D(H, sizeof(float) * ldH, c->stage, sizeof(float) * c->N, sizeof(float) * c->N, (size_t)K, hipMemcpyDeviceToHost));
     }
-    if (B) for (int i = 0; i < c->n_cov; ++i) if (B[i] && c->cov_lev[i] * c->cov_k[i] > 0)
-        HIPCHK(c, hipMemcpyAsync(B[i], c->B[c->bcur] + c->meta.boff[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (B) for (int i = 0; i < c->n_cov; ++i) if (B[i] && c->cov_lev[i] * c->cov_k[i] > 0)
+        HIPCHK(c, hipMemcpy(B[i], c->B[c->bcur] + c->meta.boff[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyDeviceToHost));
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1070,11 +1115,12 @@ static int grow_losses(alpine_ctx* c)
 {
     const int w = c->n_cov + 2;
     double* bigger = nullptr;
-    HIPCHK(c, hipMalloc((void**)&bigger, sizeof(double) * c->loss_cap * 2 * w));
+    int rc = dev_alloc(c, reinterpret_cast<void**>(&bigger), sizeof(double) * c->loss_cap * 2 * w, false, "loss_dev");
+    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(bigger, c->loss_dev, sizeof(double) * c->loss_rows * w, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(c->loss_dev));
-    c->bytes += sizeof(double) * c->loss_cap * w;
+    c->bytes -= sizeof(double) * c->loss_cap * w;
+    HIPCHK(c, dev_free(c, c->loss_dev));
     c->loss_dev = bigger;
     c->loss_cap *= 2;
     return 0;

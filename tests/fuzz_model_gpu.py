@@ -1,0 +1,177 @@
+"""Time-boxed randomised campaign at the level of the drop-in API (by hand: `python tests/fuzz_model_gpu.py --seconds 600 [--seed0 S]`).
+
+tests/fuzz_gpu.py drives the C ABI directly; this one goes through `ALPINE(**params).fit(adata, covariate_keys, batch_size, max_iter,
+sampling_method)` + `transform` + `compute_loss` with random constructor arguments, label columns (object dtype, missing values,
+one-level covariates, covariates without guided components), full-batch / mini-batch / weighted epochs, the block-coordinate branch,
+scaling on or off and every `x_dtype` the configuration admits -- i.e. the host logic of alpine_amd/model.py (encoders, sampler replay,
+index streams, dtype selection, residency) on top of the kernels -- against the oracle's op-for-op restatement of the reference
+(`fit_faithful_batches`, pinned by the reference's golden vectors: tests/test_oracle_golden.py), started from the same seed.  The unseeded
+`transform` must draw the H the reference would draw (same position of the global torch generator after `fit`)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import pandas as pd
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from _golden import rel_fro                      # noqa: E402
+from oracle import alpine_oracle as orc          # noqa: E402
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    G = int(rng.integers(5, 500))
+    N = int(rng.integers(12, 2500))
+    n_cov = int(rng.integers(1, 4))                                  # the reference needs at least one covariate (sampling.py:40)
+    ks = [int(rng.integers(0, 7)) for _ in range(n_cov)]
+    levels = [int(rng.choice([1, 2, 3, 5])) for _ in range(n_cov)]
+    Ku = int(rng.choice([1, 2, 6, 20, 33, 64, 90])) if rng.random() < 0.85 else int(rng.integers(129, 200))
+    Ku = max(1, min(Ku, 256 - sum(ks)))
+    loss = ["kl-divergence", "frobenius"][int(rng.integers(0, 2))]
+    reg = rng.random() < 0.5
+    kind = str(rng.choice(["gamma", "counts", "sparse"]))
+    X = rng.gamma(0.5, 2.0, size=(N, G)).astype(np.float32)
+    if kind == "counts":
+        X = np.floor(X * 3).astype(np.float32)
+    elif kind == "sparse":
+        X = (X * (rng.random(size=X.shape) < 0.15)).astype(np.float32)
+    obs = {}
+    for i, C in enumerate(levels):
+        lab = np.array([f"L{j}" for j in rng.integers(0, C, size=N)], dtype=object)
+        if C > 1 and rng.random() < 0.5:
+            lab[rng.random(N) < float(rng.choice([0.02, 0.3]))] = np.nan
+        obs[f"c{i}"] = lab
+    params = dict(n_components=Ku, n_covariate_components=ks, lam=[float(rng.choice([1.0, 50.0, 1e3])) for _ in ks],
+                  orth_W=0.1 if reg else 0.0, alpha_W=0.7 if reg else 0.0, l1_ratio_W=0.4 if reg else 0.0, loss_type=loss,
+                  use_als=bool(rng.random() < 0.25), scale_needed=bool(rng.random() < 0.7), random_state=int(seed % 10007),
+                  eps=float(rng.choice([1e-6, 1e-8])))
+    u = rng.random()
+    batch_size = None if u < 0.5 else int(rng.integers(max(2, N // 6), N + 1))
+    sampling = "weighted" if rng.random() < 0.4 else "random"
+    T = int(rng.integers(2, 6))
+    wide = Ku + sum(ks) > 128
+    dtypes = ["auto", "x3", "f32"] + ([] if (wide or batch_size is not None or sampling == "weighted" or kind != "counts") else ["split"])
+    x_dtype = str(rng.choice(dtypes))
+    n_t = int(rng.integers(3, N + 1))
+    return params, X, pd.DataFrame(obs), batch_size, sampling, T, x_dtype, n_t, kind
+
+
+def run_case(seed, model_only=False, oracle_only=False, pause=0.0):
+    from alpine_amd import ALPINE, MiniAnnData
+    params, X, obs, bs, sampling, T, x_dtype, n_t, kind = make_case(seed)
+    keys = list(obs.columns)
+    tag = (f"seed {seed}: G={X.shape[1]} N={X.shape[0]} K={params['n_components']}+{params['n_covariate_components']} {params['loss_type'][:2]} "
+           f"als={int(params['use_als'])} scale={int(params['scale_needed'])} bs={bs} {sampling} T={T} x={x_dtype} X={kind}")
+    if oracle_only:                                                  # (debugging aid: the CPU side alone, no device work at all)
+        from alpine_amd.encoder import FeatureEncoders
+        Ys = [np.asarray(y).T for y in FeatureEncoders(keys).fit_transform(obs)]
+        p = orc.OracleParams(**{k: v for k, v in params.items() if k != "scale_needed"})
+        s = orc.init_factors(p, np.ascontiguousarray(X.T), [y.T for y in Ys])
+        orc.fit_faithful_batches(p, s, T, bs, sampling)
+        if params["scale_needed"]:
+            orc.scale_factors(p, s)
+        H0t = torch.rand((p.total_components, n_t), dtype=torch.float32)
+        orc.transform_faithful(p.eps, s.W, torch.tensor(np.ascontiguousarray(X[:n_t].T)), H0t, 3).numpy()
+        return
+    adata = MiniAnnData(X.copy(), obs.copy())
+    model = ALPINE(device="cuda:0", x_dtype=x_dtype, **params).fit(adata, covariate_keys=keys, batch_size=bs, max_iter=T, sampling_method=sampling)
+    a_t = MiniAnnData(X[:n_t].copy(), obs.iloc[:n_t].copy())
+    model.transform(a_t, n_iter=3)                                   # unseeded: continues the generator where fit left it
+    Ht = np.concatenate([np.asarray(a_t.obsm[k]).T for k in keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0)
+    cl = model.compute_loss(adata)
+    if model_only:                                                   # (debugging aid: the device side alone)
+        return
+    if pause:
+        time.sleep(pause)
+
+    p = orc.OracleParams(**{k: v for k, v in params.items() if k != "scale_needed"})
+    Ys = [np.asarray(y) for y in model.matrices["Ys"]]              # C_i x N as encoded by the model (encoder parity: tests/test_host_api.py)
+    s = orc.init_factors(p, np.ascontiguousarray(X.T), [y.T for y in Ys])
+    orc.fit_faithful_batches(p, s, T, bs, sampling)
+    want_loss = np.array(s.losses)
+    if params["scale_needed"]:
+        orc.scale_factors(p, s)
+    H0t = torch.rand((p.total_components, n_t), dtype=torch.float32)
+    want_Ht = orc.transform_faithful(p.eps, s.W, torch.tensor(np.ascontiguousarray(X[:n_t].T)), H0t, 3).numpy()
+
+    W = np.concatenate(model.matrices["Ws"], axis=1)
+    H = np.concatenate(model.matrices["Hs"], axis=0)
+    tol = 2e-5 * max(2, T) * (3 if bs is not None else 1)
+    Wo32, Ho32 = s.W.numpy(), s.H.numpy()
+    if not (np.isfinite(Wo32).all() and np.isfinite(Ho32).all()):
+        # degenerate fits are the reference's to define (a component whose column of W sums to zero turns into NaN in
+        # _scale_matrices -- e.g. an L1 penalty that empties W on sparse data): the library must put NaN where the reference does
+        assert np.array_equal(np.isnan(W), np.isnan(Wo32)) and np.array_equal(np.isnan(H), np.isnan(Ho32)), tag + ": NaN pattern differs from the reference's"
+        ok = rel_fro(np.nan_to_num(W), np.nan_to_num(Wo32)) < 1e-3 if np.nan_to_num(Wo32).any() else not np.nan_to_num(W).any()
+        assert ok, tag + ": finite part of W"
+        print(f"{tag} | degenerate fit (NaN after scaling, as the reference): pattern equal", flush=True)
+        return
+    eW, eH = rel_fro(W, Wo32), rel_fro(H, Ho32)
+    assert np.isfinite(W).all() and np.isfinite(H).all(), tag + ": non-finite factors"
+    assert eW < tol and eH < tol, f"{tag}: W {eW:.2e} H {eH:.2e}"
+    for b, bo in zip(model.matrices["Bs"], s.Bs):
+        if bo.numel():
+            assert rel_fro(np.asarray(b), bo.numpy()) < 5 * tol, f"{tag}: B {rel_fro(np.asarray(b), bo.numpy()):.2e}"
+    got_loss = model.loss_history.to_numpy(dtype=np.float64)
+    assert got_loss.shape == want_loss.shape, f"{tag}: loss rows {got_loss.shape} vs {want_loss.shape}"
+    # the oracle's rows restate the reference's float32 torch.norm: good to ~1e-4 at these sizes
+    np.testing.assert_allclose(got_loss[:, :2], want_loss[:, :2], rtol=5e-4, err_msg=tag)
+    eT = rel_fro(Ht, want_Ht)
+    assert eT < 10 * tol, f"{tag}: transform {eT:.2e}"
+    # compute_loss(adata) (main.py:187-236) in float64 from the ORACLE's final factors: recon + sum lam_i pred_i (scaling leaves both unchanged)
+    Wo, Ho = s.W.numpy().astype(np.float64), s.H.numpy().astype(np.float64)
+    want_cl = orc.recon_loss_f64(np.ascontiguousarray(X.T), s.W.numpy(), s.H.numpy())
+    off = 0
+    for i, k in enumerate(p.n_covariate_components):
+        y, yh = Ys[i].astype(np.float64), s.Bs[i].numpy().astype(np.float64) @ Ho[off:off + k]
+        if p.loss_type == "kl-divergence":
+            yh = np.clip(yh, p.eps, None)
+            pl = float(np.sum(y * np.log(np.clip(y / yh, p.eps, None)) - y + yh))
+        else:
+            pl = float(np.sum((y - yh) ** 2))
+        want_cl += p.lam[i] * pl
+        off += k
+    assert abs(cl - want_cl) <= 1e-3 * abs(want_cl) + 1e-3, f"{tag}: compute_loss {cl!r} vs {want_cl!r}"
+    print(f"{tag} | W {eW:.1e} H {eH:.1e} transform {eT:.1e}", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed0", type=int, default=40000)
+    ap.add_argument("--cases", type=int, default=10 ** 9)
+    ap.add_argument("--repeat", type=int, default=1, help="run every seed this many times (debugging aid)")
+    ap.add_argument("--model-only", action="store_true", help="skip the oracle comparison (debugging aid)")
+    ap.add_argument("--oracle-only", action="store_true", help="only the CPU oracle, no device work (debugging aid)")
+    ap.add_argument("--pause", type=float, default=0.0, help="seconds to sleep between the device part and the oracle part (debugging aid)")
+    ap.add_argument("--no-skip", action="store_true", help="replay torch.randperm by calling it (debugging aid)")
+    ap.add_argument("--threads", type=int, default=0, help="torch CPU threads (debugging aid)")
+    ap.add_argument("--serial-check", action="store_true", help="non-negativity check of X without the thread pool (debugging aid)")
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads or max(1, min(16, os.cpu_count() or 1)))
+    if a.no_skip:
+        import alpine_amd.model as _m
+        _m._RANDPERM_SKIP_OK = False
+    if a.serial_check:
+        import alpine_amd.model as _m
+        _m.all_nonnegative = lambda X: bool(np.asarray(X).min() >= 0)
+    t0 = time.perf_counter()
+    n = 0
+    while n < a.cases and time.perf_counter() - t0 < a.seconds:
+        try:
+            for _ in range(a.repeat):
+                run_case(a.seed0 + n, a.model_only, a.oracle_only, a.pause)
+        except AssertionError as e:
+            print(f"MISMATCH at seed {a.seed0 + n}: {e}", flush=True)
+            sys.exit(1)
+        n += 1
+    print(f"{n} cases passed in {time.perf_counter() - t0:.0f} s (seeds {a.seed0}..{a.seed0 + n - 1})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
