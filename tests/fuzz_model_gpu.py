@@ -58,6 +58,7 @@ def make_case(seed):
     dtypes = ["auto", "x3", "f32"] + ([] if (wide or batch_size is not None or sampling == "weighted" or kind != "counts") else ["split"])
     x_dtype = str(rng.choice(dtypes))
     n_t = int(rng.integers(3, N + 1))
+    params["keep_resident"] = bool(rng.random() < 0.3)                 # (extension of the reference: X stays in HBM for transform / compute_loss)
     return params, X, pd.DataFrame(obs), batch_size, sampling, T, x_dtype, n_t, kind
 
 
@@ -66,11 +67,11 @@ def run_case(seed, model_only=False, oracle_only=False, pause=0.0):
     params, X, obs, bs, sampling, T, x_dtype, n_t, kind = make_case(seed)
     keys = list(obs.columns)
     tag = (f"seed {seed}: G={X.shape[1]} N={X.shape[0]} K={params['n_components']}+{params['n_covariate_components']} {params['loss_type'][:2]} "
-           f"als={int(params['use_als'])} scale={int(params['scale_needed'])} bs={bs} {sampling} T={T} x={x_dtype} X={kind}")
+           f"als={int(params['use_als'])} scale={int(params['scale_needed'])} res={int(params['keep_resident'])} bs={bs} {sampling} T={T} x={x_dtype} X={kind}")
     if oracle_only:                                                  # (debugging aid: the CPU side alone, no device work at all)
         from alpine_amd.encoder import FeatureEncoders
         Ys = [np.asarray(y).T for y in FeatureEncoders(keys).fit_transform(obs)]
-        p = orc.OracleParams(**{k: v for k, v in params.items() if k != "scale_needed"})
+        p = orc.OracleParams(**{k: v for k, v in params.items() if k not in ("scale_needed", "keep_resident")})
         s = orc.init_factors(p, np.ascontiguousarray(X.T), [y.T for y in Ys])
         orc.fit_faithful_batches(p, s, T, bs, sampling)
         if params["scale_needed"]:
@@ -84,12 +85,22 @@ def run_case(seed, model_only=False, oracle_only=False, pause=0.0):
     model.transform(a_t, n_iter=3)                                   # unseeded: continues the generator where fit left it
     Ht = np.concatenate([np.asarray(a_t.obsm[k]).T for k in keys] + [np.asarray(a_t.obsm["ALPINE_embedding"]).T], axis=0)
     cl = model.compute_loss(adata)
+    Ht2 = None
+    if params["keep_resident"]:
+        # a second transform, on the fitted matrix itself: served from the resident copy when fit() kept one (single device, float32
+        # storage, full batch), by a fresh upload otherwise -- the same numbers either way; then the scores helper, then an explicit release
+        a2 = MiniAnnData(adata.X, obs.copy())
+        model.transform(a2, n_iter=2)
+        Ht2 = np.concatenate([np.asarray(a2.obsm[k]).T for k in keys] + [np.asarray(a2.obsm["ALPINE_embedding"]).T], axis=0)
+        scores = model.get_covariate_gene_scores()
+        assert set(scores) == set(keys) and all(np.isfinite(np.asarray(v, dtype=np.float64)).all() or not params["scale_needed"] for v in scores.values()), tag
+        model.release()
     if model_only:                                                   # (debugging aid: the device side alone)
         return
     if pause:
         time.sleep(pause)
 
-    p = orc.OracleParams(**{k: v for k, v in params.items() if k != "scale_needed"})
+    p = orc.OracleParams(**{k: v for k, v in params.items() if k not in ("scale_needed", "keep_resident")})
     Ys = [np.asarray(y) for y in model.matrices["Ys"]]              # C_i x N as encoded by the model (encoder parity: tests/test_host_api.py)
     s = orc.init_factors(p, np.ascontiguousarray(X.T), [y.T for y in Ys])
     orc.fit_faithful_batches(p, s, T, bs, sampling)
@@ -98,6 +109,10 @@ def run_case(seed, model_only=False, oracle_only=False, pause=0.0):
         orc.scale_factors(p, s)
     H0t = torch.rand((p.total_components, n_t), dtype=torch.float32)
     want_Ht = orc.transform_faithful(p.eps, s.W, torch.tensor(np.ascontiguousarray(X[:n_t].T)), H0t, 3).numpy()
+    want_Ht2 = None
+    if Ht2 is not None and np.isfinite(s.W.numpy()).all():
+        H0t2 = torch.rand((p.total_components, X.shape[0]), dtype=torch.float32)
+        want_Ht2 = orc.transform_faithful(p.eps, s.W, torch.tensor(np.ascontiguousarray(X.T)), H0t2, 2).numpy()
 
     W = np.concatenate(model.matrices["Ws"], axis=1)
     H = np.concatenate(model.matrices["Hs"], axis=0)
@@ -123,6 +138,9 @@ def run_case(seed, model_only=False, oracle_only=False, pause=0.0):
     np.testing.assert_allclose(got_loss[:, :2], want_loss[:, :2], rtol=5e-4, err_msg=tag)
     eT = rel_fro(Ht, want_Ht)
     assert eT < 10 * tol, f"{tag}: transform {eT:.2e}"
+    if want_Ht2 is not None:
+        eT2 = rel_fro(Ht2, want_Ht2)
+        assert eT2 < 10 * tol, f"{tag}: second transform (keep_resident) {eT2:.2e}"
     # compute_loss(adata) (main.py:187-236) in float64 from the ORACLE's final factors: recon + sum lam_i pred_i (scaling leaves both unchanged)
     Wo, Ho = s.W.numpy().astype(np.float64), s.H.numpy().astype(np.float64)
     want_cl = orc.recon_loss_f64(np.ascontiguousarray(X.T), s.W.numpy(), s.H.numpy())
