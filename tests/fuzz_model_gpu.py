@@ -23,10 +23,16 @@ from _golden import rel_fro                      # noqa: E402
 from oracle import alpine_oracle as orc          # noqa: E402
 
 
+BIG = False          # --big: shapes that span several workgroup tiles, many 128-cell blocks and both tile widths (a few seconds of oracle each)
+
+
 def make_case(seed):
     rng = np.random.default_rng(seed)
     G = int(rng.integers(5, 500))
     N = int(rng.integers(12, 2500))
+    if BIG:
+        G = int(rng.choice([511, 1000, 1031, 2049, 3000]))
+        N = int(rng.choice([4097, 8191, 16385, 20000, 33000]))
     n_cov = int(rng.integers(1, 4))                                  # the reference needs at least one covariate (sampling.py:40)
     ks = [int(rng.integers(0, 7)) for _ in range(n_cov)]
     levels = [int(rng.choice([1, 2, 3, 5])) for _ in range(n_cov)]
@@ -135,7 +141,12 @@ def run_case(seed, model_only=False, oracle_only=False, pause=0.0):
     got_loss = model.loss_history.to_numpy(dtype=np.float64)
     assert got_loss.shape == want_loss.shape, f"{tag}: loss rows {got_loss.shape} vs {want_loss.shape}"
     # the oracle's rows restate the reference's float32 torch.norm: good to ~1e-4 at these sizes
-    np.testing.assert_allclose(got_loss[:, :2], want_loss[:, :2], rtol=5e-4, err_msg=tag)
+    # (at larger sizes that float32 norm is itself off by up to 1 % -- tests/fuzz_gpu.py, seed 1017 -- so the rows are then only a sanity
+    # bound and the real check is the float64 direct form of the oracle's final factors)
+    if X.size < 2e7:          # (beyond that the float32 norm of the reference is off by several per cent: 3.8 % at 2 049 x 33 000, seed 70008)
+        np.testing.assert_allclose(got_loss[:, :2], want_loss[:, :2], rtol=5e-4 if X.size < 1.5e6 else 3e-2, err_msg=tag)
+    direct = orc.recon_loss_f64(np.ascontiguousarray(X.T), Wo32, Ho32)
+    assert abs(got_loss[-1, 1] - direct) <= 2e-4 * direct + 1e-3, f"{tag}: last recon {got_loss[-1, 1]!r} vs float64 direct {direct!r}"
     eT = rel_fro(Ht, want_Ht)
     assert eT < 10 * tol, f"{tag}: transform {eT:.2e}"
     if want_Ht2 is not None:
@@ -163,6 +174,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed0", type=int, default=40000)
     ap.add_argument("--cases", type=int, default=10 ** 9)
+    ap.add_argument("--big", action="store_true", help="larger matrices (several workgroup tiles; seconds per case)")
     ap.add_argument("--repeat", type=int, default=1, help="run every seed this many times (debugging aid)")
     ap.add_argument("--model-only", action="store_true", help="skip the oracle comparison (debugging aid)")
     ap.add_argument("--oracle-only", action="store_true", help="only the CPU oracle, no device work (debugging aid)")
@@ -171,6 +183,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="torch CPU threads (debugging aid)")
     ap.add_argument("--serial-check", action="store_true", help="non-negativity check of X without the thread pool (debugging aid)")
     a = ap.parse_args()
+    global BIG
+    BIG = a.big
     torch.set_num_threads(a.threads or max(1, min(16, os.cpu_count() or 1)))
     if a.no_skip:
         import alpine_amd.model as _m
