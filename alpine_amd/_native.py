@@ -31,7 +31,9 @@ EXPORTS = [
     "alpine_als_begin", "alpine_als_group_begin", "alpine_als_group_end", "alpine_reduce_block_hht", "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_debug_set_xcd_bias", "alpine_debug_run_graph", "alpine_get_kernel_time", "alpine_read_buffer",
     "alpine_comm_get_unique_id", "alpine_comm_version", "alpine_comm_init_rank", "alpine_comm_destroy", "alpine_comm_all_reduce", "alpine_iter",
+    "alpine_comm_count", "alpine_comm_init_all", "alpine_debug_set_team_width",
 ]
+ABI_VERSION = 6          # ALPINE_HIP_ABI_VERSION of include/alpine_hip.h this binding was written against
 
 
 class AlpineConfig(C.Structure):
@@ -57,6 +59,7 @@ class AlpineInfo(C.Structure):
         ("span_rows_a", C.c_int32), ("span_rows_b", C.c_int32),
         ("spans_per_workgroup_a", C.c_int32), ("spans_per_workgroup_b", C.c_int32),
         ("xcd_bias_per_mille", C.c_int32), ("xcc_of_workgroup0", C.c_int32),
+        ("team_width_a", C.c_int32), ("team_width_b", C.c_int32),
     ]
 
 
@@ -124,6 +127,9 @@ def load() -> C.CDLL:
     lib.alpine_comm_destroy.argtypes = [p]
     lib.alpine_comm_all_reduce.argtypes = [p, i64, i64]
     lib.alpine_iter.argtypes = [p, i32]
+    lib.alpine_comm_count.argtypes = [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.alpine_comm_init_all.argtypes = [C.POINTER(p), i32]
+    lib.alpine_debug_set_team_width.argtypes = [p, i32]
     for name in EXPORTS:
         if name not in ("alpine_reduce_block_floats", "alpine_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -194,7 +200,12 @@ class NativeShard:
 
     def info(self) -> AlpineInfo:
         out = AlpineInfo()
+        out.abi_version = -1
         self._chk(self._lib.alpine_get_info(self._h, C.byref(out)))
+        if out.abi_version != ABI_VERSION:
+            # a stale build, or another library swapped in through ALPINE_HIP_LIBRARY: the struct layouts may differ
+            raise AlpineNativeError(-5, f"{LIB_PATH} reports ABI version {out.abi_version}, this binding expects {ABI_VERSION}: rebuild it "
+                                        "(python -c 'import __graft_entry__ as g; g.build()')")
         return out
 
     # -- ingest
@@ -254,6 +265,12 @@ class NativeShard:
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
         self._chk(self._lib.alpine_comm_init_rank(self._h, C.cast(buf, C.c_void_p), nranks, rank))
         self.comm_ranks, self.comm_rank = nranks, rank
+
+    def comm_count(self):
+        """(ranks, rank) as the attached communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int(-1), C.c_int(-1)
+        self._chk(self._lib.alpine_comm_count(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
 
     def comm_destroy(self):
         self._chk(self._lib.alpine_comm_destroy(self._h))
@@ -338,6 +355,9 @@ class NativeShard:
     def debug_set_xcd_bias(self, per_mille: int):
         self._chk(self._lib.alpine_debug_set_xcd_bias(self._h, int(per_mille)))
 
+    def debug_set_team_width(self, width: int):
+        self._chk(self._lib.alpine_debug_set_team_width(self._h, int(width)))
+
     def debug_run_graph(self, n_pairs: int):
         self._chk(self._lib.alpine_debug_run_graph(self._h, int(n_pairs)))
 
@@ -360,6 +380,18 @@ def comm_unique_id() -> bytes:
     if rc != 0:
         raise AlpineNativeError(rc, lib.alpine_last_error(None).decode())
     return buf.raw
+
+
+def comm_init_all(engines: Sequence["NativeShard"]) -> None:
+    """ONE process, one engine per GPU: ncclCommInitAll over the engines' devices, engine i becomes rank i (no unique id)."""
+    lib = load()
+    arr = (C.c_void_p * len(engines))(*[e._h.value for e in engines])
+    rc = lib.alpine_comm_init_all(arr, len(engines))
+    if rc != 0:
+        msg = (engines[0]._lib.alpine_last_error(engines[0]._h) or lib.alpine_last_error(None) or b"").decode()
+        raise AlpineNativeError(rc, msg or lib.alpine_last_error(None).decode())
+    for i, e in enumerate(engines):
+        e.comm_ranks, e.comm_rank = len(engines), i
 
 
 def comm_version() -> int:

@@ -75,6 +75,7 @@ struct alpine_ctx {
     float *Xb_gn = nullptr, *Xb_ng = nullptr, *Hb = nullptr, *Yb = nullptr;
     int* idx_dev = nullptr;
     int slots = 512;
+    int team_force = 0;               // alpine_debug_set_team_width: 0 = the library's own choice (team_width)
     bool x3 = false;                  // ALPINE_FLAG_X3_PRODUCTS in effect (float32 X, exact bf16 plane products)
     int64_t piecesA_cap = 0, piecesB_cap = 0;   // capacity of the pieces buffers, in floats (covers both tile widths of the x3 sweeps)
     int split_a_hint = 0, split_b_hint = 0;     // alpine_config.split_a / split_b
@@ -139,6 +140,8 @@ struct alpine_ctx {
     bool x3_narrow = false;           // 512-column workgroup tiles at K <= 64 (in effect)
     bool x3_narrow_pref = false;      // ... wanted for this shard size; alpine_finalize_X confirms it once the matrix instruction is known
     double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
+    bool x_one_plane = false;         // ... and NONE is (census of alpine_finalize_X): the K > 64 sweeps then run the form without split and zero-plane test
+    bool team_ok = true;              // teams pay for this ctx's data and model size (decided in alpine_finalize_X; see team_width)
     // profiling
     bool prof = false;
     int prof_every = 1;               // events bracket the launches of every prof_every-th phase 1 / iteration only
@@ -173,6 +176,34 @@ static int fail(alpine_ctx* c, int code, const char* fmt, ...)
         if (r_ != ncclSuccess)                                                                    \
             return fail((c), ALPINE_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
+
+// THE rule for every copy between the device and PAGEABLE host memory (caller arrays, std::vector, the stack) -- in BOTH directions:
+// drain the ctx stream, then the BLOCKING hipMemcpy / hipMemcpy2D.  Never hipMemcpyAsync + hipStreamSynchronize: for pageable memory the
+// runtime stages the bytes through a pinned buffer of its own, and the hop between that buffer and the user's memory is the runtime's
+// business, not a stream operation.  What is ESTABLISHED (round 3, tests/fuzz_model_gpu.py seed 40885 repeated, gpurun_out/r04k-r04o):
+// with device -> host copies issued as Async + synchronise the process died of heap corruption about once per 400 compute_loss calls
+// (8-byte stray writes into freed chunks: the doubles of sum_f64_partials landing in a std::vector freed two lines later; numpy shape
+// fields changing under the test); guard zones around every device buffer stayed clean, the device alone and the oracle alone survived
+// thousands of repeats; replacing ONLY those copies by this rule ended it (8 x 400 + 4 065 + 2 919 cases without a crash).  What is
+// INFERRED: that the late writer is the staging hop (no trace of the runtime's copy thread was taken).  The host -> device direction has
+// shown no symptom -- there the hazard would be the runtime READING freed or reused host memory (wrong factors, not a crash) -- but it
+// rests on the same assumption, so it follows the same rule.  All call sites go through these two helpers.
+static int host_copy(alpine_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+    if (bytes == 0) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, src, bytes, kind));
+    return 0;
+}
+static int host_copy_2d(alpine_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind)
+{
+    if (width == 0 || height == 0) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind));
+    return 0;
+}
+#define HOSTCOPY(c, ...)    do { int rc_ = host_copy((c), __VA_ARGS__); if (rc_) return rc_; } while (0)
+#define HOSTCOPY2D(c, ...)  do { int rc_ = host_copy_2d((c), __VA_ARGS__); if (rc_) return rc_; } while (0)
 
 #define DISPATCH_KT(kt, CALL)                  \
     switch (kt) {                              \
@@ -303,9 +334,19 @@ extern "C" int64_t alpine_reduce_block_floats(const alpine_config* cfg)
     return g.red_floats;
 }
 
-static SweepGeom make_geom(int64_t F, int64_t R, int slots, int forced, int bf = SG_BLOCK_F, int bias_pm = 0) { return sg_make_geom(F, R, slots, forced, bf, bias_pm); }
 constexpr int XCD_BIAS_MAG = 40;      // per mille: what the placement probe applies (alpine_finalize_X); more stops paying, see DESIGN.md 4.2c
-static inline int sweep_grid(const SweepGeom& g) { return (g.nwg + g.sub - 1) / g.sub; }
+static inline int sweep_grid(const SweepGeom& g) { return sg_grid(g); }
+
+// Team width of an x3 sweep over F columns with workgroup tiles of bf_wg columns (SweepGeom::gw): the widest team of {8, 4, 2} whose
+// tiles leave at most 2.5 % of the team members without columns (the last team tile is padded to gw workgroup tiles); 1 for every
+// other sweep kernel, for forced divisions (a test knob that counts WORKGROUPS per tile) and when the grid cannot be dealt to the
+// 8 XCDs in whole teams.  team_force > 0 (alpine_debug_set_team_width): that width whenever it is admissible.
+// Measured with tools/x3w_bench (variants interleaved, profiles/r04/x3w_bench_*.txt): K = 105 on one-plane data, teams of 8 together with
+// the one-plane kernel 1.74 -> 1.54 ms per sweep (either alone: 0 - 2 %: the sweep sat on the fabric limit AND on its issue limit);
+// K = 60 on count data -3 % (W^TX, 8) / -4 % (XH^T, 4); K <= 64 on full significands teams LOSE 2 - 15 % (there the chip is at its
+// power limit and lock-step neighbours make it worse), K = 105 on full significands +-1 %.  Hence team_ok (alpine_finalize_X).
+static int team_width(const alpine_ctx* c, int64_t F, int bf_wg, int forced);
+static SweepGeom make_geom(const alpine_ctx* c, int64_t F, int64_t R, int forced, int bf_wg, int bias_pm = 0, int gw = 0);
 
 static int gram_rows_per_wave(int64_t R, int n_cu)
 {
@@ -318,9 +359,31 @@ static int gram_rows_per_wave(int64_t R, int n_cu)
 static void apply_sweep_geometry(alpine_ctx* c, int bf)
 {
     c->sweep_bf = bf;
-    c->geomA = make_geom(c->Gp, c->Np, c->slots, c->split_a_hint, bf, c->xcd_bias_pm);       // XH^T: f = genes, r = cells
-    c->geomB = make_geom(c->Np, c->Gp, c->slots, c->split_b_hint, bf, c->xcd_bias_pm);       // W^TX: f = cells, r = genes
+    c->geomA = make_geom(c, c->Gp, c->Np, c->split_a_hint, bf, c->xcd_bias_pm);       // XH^T: f = genes, r = cells
+    c->geomB = make_geom(c, c->Np, c->Gp, c->split_b_hint, bf, c->xcd_bias_pm);       // W^TX: f = cells, r = genes
     c->full.gA = c->geomA; c->full.gB = c->geomB;
+}
+
+static int team_width(const alpine_ctx* c, int64_t F, int bf_wg, int forced)
+{
+    if (!c->x3 || forced > 0) return 1;
+    if (c->team_force == 0 && !c->team_ok) return 1;
+    const int64_t tiles = (F + bf_wg - 1) / bf_wg;
+    auto admissible = [&](int gw) { return gw >= 1 && c->slots % (8 * gw) == 0; };
+    if (c->team_force > 0) return admissible(c->team_force) ? c->team_force : 1;
+    for (int gw : {8, 4, 2}) {
+        if (!admissible(gw)) continue;
+        const int64_t padded = (tiles + gw - 1) / gw * gw;
+        if ((padded - tiles) * 40 <= padded) return gw;
+    }
+    return 1;
+}
+
+static SweepGeom make_geom(const alpine_ctx* c, int64_t F, int64_t R, int forced, int bf_wg, int bias_pm, int gw)
+{
+    if (gw <= 0) gw = team_width(c, F, bf_wg, forced);
+    else if (!c->x3 || forced > 0 || c->slots % (8 * gw) != 0) gw = 1;
+    return sg_make_geom(F, R, std::max(1, c->slots / gw), forced, bf_wg * gw, bias_pm, gw);
 }
 
 // ---------------------------------------------------------------------------------- create
@@ -397,8 +460,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         }
         ALLOC(c, c->xcc_dev, int, 4);
         ALLOC(c, c->rowtab, GuidedRow, 32);
-        HIPCHK(c, hipMemcpyAsync(c->rowtab, rows, sizeof rows, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HOSTCOPY(c, c->rowtab, rows, sizeof rows, hipMemcpyHostToDevice);
     }
 
     const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
@@ -426,19 +488,23 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     auto piece_floats = [&](int bf, int64_t* capA, int64_t* capB) {
         // every even/odd bias the ctx may end up with (the placement probe of alpine_finalize_X picks -+XCD_BIAS_MAG; a bias moves the
         // last share's boundary AND can add a piece per span: maxp depends on the longer span)
+        // ... and every team width (the library's own choice = 0, and the widths alpine_debug_set_team_width may ask for)
         int64_t ta = 0, tb = 0;
-        for (int bias : {c->xcd_bias_pm, 0, -XCD_BIAS_MAG, XCD_BIAS_MAG}) {
-            const SweepGeom a = make_geom(Gp, Np, slots, cfg->split_a, bf, bias), b = make_geom(Np, Gp, slots, cfg->split_b, bf, bias);
-            ta = std::max<int64_t>(ta, (int64_t)a.nwg * a.maxp); tb = std::max<int64_t>(tb, (int64_t)b.nwg * b.maxp);
-        }
-        if (c->batch_cap > 0) {
-            const int64_t Bp_max = round_up(std::min<int64_t>(c->batch_cap, (int64_t)1 << 30), 128);
-            for (int64_t Bp = 128; Bp <= Bp_max; Bp += 128) {
-                const SweepGeom va = make_geom(Gp, Bp, slots, 0, bf), vb = make_geom(Bp, Gp, slots, 0, bf);
-                ta = std::max<int64_t>(ta, (int64_t)va.nwg * va.maxp); tb = std::max<int64_t>(tb, (int64_t)vb.nwg * vb.maxp);
+        auto tiles = [](const SweepGeom& g) { return (int64_t)g.nwg * g.maxp * g.bf; };
+        for (int gw : {0, 1, 2, 4, 8}) {
+            for (int bias : {c->xcd_bias_pm, 0, -XCD_BIAS_MAG, XCD_BIAS_MAG}) {
+                ta = std::max(ta, tiles(make_geom(c, Gp, Np, cfg->split_a, bf, bias, gw)));
+                tb = std::max(tb, tiles(make_geom(c, Np, Gp, cfg->split_b, bf, bias, gw)));
+            }
+            if (c->batch_cap > 0) {
+                const int64_t Bp_max = round_up(std::min<int64_t>(c->batch_cap, (int64_t)1 << 30), 128);
+                for (int64_t Bp = 128; Bp <= Bp_max; Bp += 128) {
+                    ta = std::max(ta, tiles(make_geom(c, Gp, Bp, 0, bf, 0, gw)));
+                    tb = std::max(tb, tiles(make_geom(c, Bp, Gp, 0, bf, 0, gw)));
+                }
             }
         }
-        *capA = std::max(*capA, ta * bf * KP); *capB = std::max(*capB, tb * bf * KP);
+        *capA = std::max(*capA, ta * KP); *capB = std::max(*capB, tb * KP);
     };
     const int bf_default = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
     piece_floats(bf_default, &c->piecesA_cap, &c->piecesB_cap);
@@ -507,11 +573,11 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         ALLOC(c, c->statPartH, float, (int64_t)c->tail_blocks * std::max(1, c->nstat));
     }
     ALLOC(c, c->kind, int, kind.size());
-    HIPCHK(c, hipMemcpyAsync(c->kind, kind.data(), sizeof(int) * kind.size(), hipMemcpyHostToDevice, c->stream));
+    HOSTCOPY(c, c->kind, kind.data(), sizeof(int) * kind.size(), hipMemcpyHostToDevice);
     c->ndot = (int)((c->G + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4)) * 4;
     ALLOC(c, c->dotpart, double, c->ndot);
     ALLOC(c, c->lam_dev, double, std::max(1, c->n_cov));
-    if (c->n_cov) HIPCHK(c, hipMemcpyAsync(c->lam_dev, c->lam.data(), sizeof(double) * c->n_cov, hipMemcpyHostToDevice, c->stream));
+    if (c->n_cov) HOSTCOPY(c, c->lam_dev, c->lam.data(), sizeof(double) * c->n_cov, hipMemcpyHostToDevice);
     c->loss_cap = 1024;
     ALLOC(c, c->loss_dev, double, c->loss_cap * (c->n_cov + 2));
     c->f64part_n = 65536;
@@ -531,7 +597,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         ALLOC(c, c->Yb, float, (int64_t)std::max(1, c->nYrows) * Bp);
         ALLOC(c, c->idx_dev, int, Bp);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // kind[] / lam[] host vectors go out of scope
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -582,6 +648,7 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     info->span_rows_a = c->geomA.L; info->span_rows_b = c->geomB.L;
     info->spans_per_workgroup_a = c->geomA.sub; info->spans_per_workgroup_b = c->geomB.sub;
     info->xcd_bias_per_mille = c->xcd_bias_pm; info->xcc_of_workgroup0 = c->xcc_of_wg0;
+    info->team_width_a = c->geomA.gw; info->team_width_b = c->geomB.gw;
     return 0;
 }
 
@@ -683,8 +750,7 @@ extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout
         const int64_t step = std::max<int64_t>(8, c->stage_floats / G / 8 * 8);   // multiple of 8 cells: the bf16 paths pack 8 cells per granule
         for (int64_t r = 0; r < n; r += step) {
             const int64_t m = std::min(step, n - r);
-            HIPCHK(c, hipStreamSynchronize(c->stream));         // staging buffer is reused
-            HIPCHK(c, hipMemcpy2D(c->stage, sizeof(float) * G, host + r * ld, sizeof(float) * ld, sizeof(float) * G, (size_t)m, hipMemcpyHostToDevice));
+            HOSTCOPY2D(c, c->stage, sizeof(float) * G, host + r * ld, sizeof(float) * ld, sizeof(float) * G, (size_t)m, hipMemcpyHostToDevice);   // (the drain also frees the staging buffer for reuse)
             rc = upload_x_dev(c, c->stage, layout, G, cell0 + r, m);
             if (rc) return rc;
         }
@@ -692,8 +758,7 @@ extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout
         const int64_t step = std::max<int64_t>(8, c->stage_floats / G / 8 * 8);      // cells per piece (multiple of 8)
         for (int64_t r = 0; r < n; r += step) {
             const int64_t m = std::min(step, n - r);
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, hipMemcpy2D(c->stage, sizeof(float) * m, host + r, sizeof(float) * ld, sizeof(float) * m, (size_t)G, hipMemcpyHostToDevice));
+            HOSTCOPY2D(c, c->stage, sizeof(float) * m, host + r, sizeof(float) * ld, sizeof(float) * m, (size_t)G, hipMemcpyHostToDevice);
             rc = upload_x_dev(c, c->stage, layout, m, cell0 + r, m);
             if (rc) return rc;
         }
@@ -705,13 +770,8 @@ extern "C" int alpine_upload_X_host(alpine_ctx* c, const float* host, int layout
 
 static int sum_f64_partials(alpine_ctx* c, int n, double* out)
 {
-    // device -> pageable host memory: the stream is drained first and the copy is the BLOCKING call.  (hipMemcpyAsync into a pageable
-    // buffer followed by hipStreamSynchronize is not a guarantee on this platform that the bytes have landed when the synchronise
-    // returns: the last hop, staging buffer -> user buffer, may run afterwards -- into a std::vector that has already been freed.
-    // tests/fuzz_model_gpu.py: stray 8-byte writes into freed heap chunks, about one process crash per 400 compute_loss calls.)
     std::vector<double> h(n);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(h.data(), c->f64part, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HOSTCOPY(c, h.data(), c->f64part, sizeof(double) * n, hipMemcpyDeviceToHost);          // (the rule: see host_copy)
     double s = 0;
     for (double v : h) s += v;
     *out = s;
@@ -735,8 +795,7 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
     const int blocks = (int)std::min<int64_t>(4096, (n4 + 255) / 256);
     if (c->split) {
         int h[2] = {0, 0};
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy(h, c->xflags, sizeof h, hipMemcpyDeviceToHost));
+        HOSTCOPY(c, h, c->xflags, sizeof h, hipMemcpyDeviceToHost);
         if (h[0]) return fail(c, ALPINE_ERR_UNSUPPORTED, "X is not exactly representable as the sum of two bf16 planes (more than 16 significant bits): use the float32 layout");
         c->npx = h[1] ? 2 : 1;        // small integer counts: the second plane is all zero and is never read
         if (c->npx == 1) {            // ... so give its memory back
@@ -757,14 +816,18 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         // significands all six products run, the chip lowers its clock under the matrix load, and the 16x16x32 form (x3w)
         // holds a higher clock: ~5 % faster.  Both are float32-grade; they differ in summation order only.
         std::vector<double> h(2 * (size_t)blocks);
-        HIPCHK(c, hipMemcpy(h.data(), c->f64part, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        HOSTCOPY(c, h.data(), c->f64part, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
         double multi = 0;
         for (int b = 0; b < blocks; ++b) multi += h[(size_t)blocks + b];
         c->x_multi_plane_frac = multi / ((double)c->G * (double)c->N);
+        c->x_one_plane = multi == 0.0;                     // the census counts elements: an exact zero means EVERY element is one bf16 plane
         // (wide models with an all-padding 16-component tile -- K = 105 -> 7 of 8 tiles -- are matrix-pipe-bound in both data
         // regimes and x3w never multiplies that tile: 11 % faster on full significands, 5 % on counts at K = 105)
         const bool pad_tile = c->K <= c->KP - 16;
-        c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3)));
+        // (K > 64 on one-plane data: x3w's one-plane form -- no split, no zero-plane test -- with or without a padding tile)
+        c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3) || (c->x_one_plane && c->KT >= 3)));
+        const bool team_ok = c->KT >= 3 || c->x_multi_plane_frac <= 0.01;
+        if (c->x3 && team_ok != c->team_ok) { c->team_ok = team_ok; apply_sweep_geometry(c, c->sweep_bf); c->tail_valid = false; }
         if (c->x3 && c->KT <= 2) {
             // tile width (see alpine_create): 512 columns only for small shards on the 32x32x16 form
             const bool narrow = c->x3_narrow_pref && (!c->x3_wide || std::getenv("ALPINE_HIP_X3_NARROW") != nullptr);
@@ -785,8 +848,7 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         c->probe_placement = false;
         if (rc) return rc;
         int h = -1;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy(&h, c->xcc_dev, sizeof(int), hipMemcpyDeviceToHost));      // blocking (see sum_f64_partials)
+        HOSTCOPY(c, &h, c->xcc_dev, sizeof(int), hipMemcpyDeviceToHost);
         c->xcc_of_wg0 = h;
         const int bias = h < 0 ? 0 : ((h & 1) ? -XCD_BIAS_MAG : XCD_BIAS_MAG);      // workgroup 0 on an odd XCC: the even workgroups are the slow ones
         if (bias != c->xcd_bias_pm) {
@@ -812,9 +874,8 @@ extern "C" int alpine_upload_Y(alpine_ctx* c, int cov, const float* host, int64_
     if (cov < 0 || cov >= c->n_cov) return fail(c, ALPINE_ERR_BAD_ARG, "covariate index %d out of range", cov);
     if (!host || ld < c->N) return fail(c, ALPINE_ERR_BAD_ARG, "bad Y pointer / ld");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy2D(c->Y + (int64_t)c->meta.yoff[cov] * c->Np, sizeof(float) * c->Np, host, sizeof(float) * ld,
-                          sizeof(float) * c->N, (size_t)c->cov_lev[cov], hipMemcpyHostToDevice));
+    HOSTCOPY2D(c, c->Y + (int64_t)c->meta.yoff[cov] * c->Np, sizeof(float) * c->Np, host, sizeof(float) * ld,
+               sizeof(float) * c->N, (size_t)c->cov_lev[cov], hipMemcpyHostToDevice);
     c->y_set[cov] = true;
     c->tail_valid = false;
     return 0;
@@ -826,33 +887,30 @@ extern "C" int alpine_set_factors(alpine_ctx* c, const float* W, const float* H,
     if (!W || !H || ldH < c->N || (c->n_cov > 0 && !B)) return fail(c, ALPINE_ERR_BAD_ARG, "bad factor pointers / ldH");
     HIPCHK(c, hipSetDevice(c->device));
     const int K = c->K, KP = c->KP;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     // W: G x K -> [Gp][KP]   (wide: column half h -> [h][Gp][128])
     const int halves = c->wide ? 2 : 1, kph = c->wide ? WIDE_KH : KP;
     HIPCHK(c, hipMemsetAsync(c->W, 0, sizeof(float) * c->Gp * KP, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->stage, W, sizeof(float) * (size_t)c->G * K, hipMemcpyHostToDevice, c->stream));
+    HOSTCOPY(c, c->stage, W, sizeof(float) * (size_t)c->G * K, hipMemcpyHostToDevice);
     for (int h = 0; h < halves; ++h) {
         const int kh = std::min(kph, K - h * kph);
         const int64_t n = (int64_t)c->G * kh;
         hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->stage + h * kph, (int64_t)K,
                            c->W + (int64_t)h * c->Gp * kph, kph, (int64_t)c->G, kh);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    // H: K x N (ldH) -> [Np][KP] cell-major   (wide: row block h of H -> [h][Np][128])
+    // H: K x N (ldH) -> [Np][KP] cell-major   (wide: row block h of H -> [h][Np][128]); the helper's drain also ends the kernels that read the staged W
     HIPCHK(c, hipMemsetAsync(c->H, 0, sizeof(float) * c->Np * KP, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(c->stage, sizeof(float) * c->N, H, sizeof(float) * ldH, sizeof(float) * c->N, (size_t)K, hipMemcpyHostToDevice, c->stream));
+    HOSTCOPY2D(c, c->stage, sizeof(float) * c->N, H, sizeof(float) * ldH, sizeof(float) * c->N, (size_t)K, hipMemcpyHostToDevice);
     for (int h = 0; h < halves; ++h) {
         const int kh = std::min(kph, K - h * kph);
         dim3 grid((unsigned)((c->N + 31) / 32), (kh + 31) / 32);
         hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->stage + (int64_t)h * kph * c->N, (int64_t)c->N,
                            c->H + (int64_t)h * c->Np * kph, (int64_t)kph, kh, c->N);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bcur = 0;
     for (int i = 0; i < c->n_cov; ++i) {
         if (c->cov_lev[i] * c->cov_k[i] == 0) continue;                       // k_i = 0: B_i is C_i x 0
         if (!B[i]) return fail(c, ALPINE_ERR_BAD_ARG, "B[%d] is NULL", i);
-        HIPCHK(c, hipMemcpyAsync(c->B[0] + c->meta.boff[i], B[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyHostToDevice, c->stream));
+        HOSTCOPY(c, c->B[0] + c->meta.boff[i], B[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyHostToDevice);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -877,8 +935,7 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
             hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->W + (int64_t)h * c->Gp * kph, kph,
                                c->stage + h * kph, (int64_t)K, (int64_t)c->G, kh);
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy(W, c->stage, sizeof(float) * (size_t)c->G * K, hipMemcpyDeviceToHost));      // blocking copies into caller memory (see sum_f64_partials)
+        HOSTCOPY(c, W, c->stage, sizeof(float) * (size_t)c->G * K, hipMemcpyDeviceToHost);
     }
     if (H) {
         for (int h = 0; h < halves; ++h) {
@@ -887,12 +944,10 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
             hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->H + (int64_t)h * c->Np * kph, (int64_t)kph,
                                c->stage + (int64_t)h * kph * c->N, (int64_t)c->N, c->N, kh);
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy2D(H, sizeof(float) * ldH, c->stage, sizeof(float) * c->N, sizeof(float) * c->N, (size_t)K, hipMemcpyDeviceToHost));
+        HOSTCOPY2D(c, H, sizeof(float) * ldH, c->stage, sizeof(float) * c->N, sizeof(float) * c->N, (size_t)K, hipMemcpyDeviceToHost);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (B) for (int i = 0; i < c->n_cov; ++i) if (B[i] && c->cov_lev[i] * c->cov_k[i] > 0)
-        HIPCHK(c, hipMemcpy(B[i], c->B[c->bcur] + c->meta.boff[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyDeviceToHost));
+        HOSTCOPY(c, B[i], c->B[c->bcur] + c->meta.boff[i], sizeof(float) * c->cov_lev[i] * c->cov_k[i], hipMemcpyDeviceToHost);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -995,12 +1050,17 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
 #define X3W_LAUNCH(KT_, NH_) do { \
                 if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_, 2 * KT_ - 1>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); \
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, NH_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); } while (0)
+#define X3W_LAUNCH1(KT_) do {     /* every element of X is exactly one bf16 plane (census): the form without split and test */ \
+                if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, 1, 2 * KT_ - 1, true>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); \
+                else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, 1, 2 * KT_, true>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); } while (0)
+            const bool one_plane = c->x_one_plane && !c->wide && c->x3_variant < 0;
             switch (c->KT) {
                 case 1: if (c->x3_narrow) X3W_LAUNCH(1, 1); else X3W_LAUNCH(1, 2); break;
                 case 2: if (c->x3_narrow) X3W_LAUNCH(2, 1); else X3W_LAUNCH(2, 2); break;
-                case 3: X3W_LAUNCH(3, 1); break;
-                default: X3W_LAUNCH(4, 1); break;
+                case 3: if (one_plane) X3W_LAUNCH1(3); else X3W_LAUNCH(3, 1); break;
+                default: if (one_plane) X3W_LAUNCH1(4); else X3W_LAUNCH(4, 1); break;
             }
+#undef X3W_LAUNCH1
 #undef X3W_LAUNCH
             HIPCHK(c, hipGetLastError());
             return 0;
@@ -1627,6 +1687,41 @@ extern "C" int alpine_comm_init_rank(alpine_ctx* c, const void* id, int nranks, 
     return 0;
 }
 
+// What the ATTACHED communicator itself says (ncclCommCount / ncclCommUserRank), not what alpine_comm_init_rank was told: a run report
+// that prints these shows that RCCL saw N ranks (bench.py fails the run when they disagree with the launch).
+extern "C" int alpine_comm_count(alpine_ctx* c, int* nranks_out, int* rank_out)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (!c->comm) return fail(c, ALPINE_ERR_STATE, "no communicator attached (alpine_comm_init_rank / alpine_comm_init_all)");
+    int n = -1, r = -1;
+    NCCLCHK(c, ncclCommCount(c->comm, &n));
+    NCCLCHK(c, ncclCommUserRank(c->comm, &r));
+    if (nranks_out) *nranks_out = n;
+    if (rank_out) *rank_out = r;
+    return 0;
+}
+
+// ONE process, n ctxs on n different GPUs (the single-process drop-in of SURVEY.md 8b: ALPINE(devices=[...]), examples/fit_c --devices):
+// ncclCommInitAll over the ctxs' devices, communicator i attached to ctxs[i] as rank i.  No unique id, no launcher.  Each ctx is then
+// driven by its own host thread (alpine_run & co. enqueue the all-reduce on the ctx's stream; the ranks meet inside RCCL).
+extern "C" int alpine_comm_init_all(alpine_ctx* const* ctxs, int n)
+{
+    if (!ctxs || n < 1 || n > 64) return fail(nullptr, ALPINE_ERR_BAD_ARG, "alpine_comm_init_all: bad arguments (n = %d)", n);
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(nullptr, ALPINE_ERR_BAD_ARG, "alpine_comm_init_all: ctxs[%d] is NULL", i);
+        if (ctxs[i]->comm) return fail(ctxs[i], ALPINE_ERR_STATE, "the ctx already has a communicator");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j]->device == ctxs[i]->device)
+                return fail(ctxs[i], ALPINE_ERR_BAD_ARG, "alpine_comm_init_all: ctxs %d and %d share device %d (RCCL needs one GPU per rank)", j, i, ctxs[i]->device);
+    }
+    std::vector<int> devs(n);
+    std::vector<ncclComm_t> comms(n, nullptr);
+    for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+    NCCLCHK(ctxs[0], ncclCommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_ranks = n; ctxs[i]->comm_rank = i; }
+    return 0;
+}
+
 extern "C" int alpine_comm_destroy(alpine_ctx* c)
 {
     if (!c) return ALPINE_ERR_BAD_ARG;
@@ -1712,8 +1807,7 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
         if (idx[j] < 0 || idx[j] >= c->N) return fail(c, ALPINE_ERR_BAD_ARG, "batch index %lld out of range", (long long)idx[j]);
         h[(size_t)j] = (int)idx[j];
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));           // idx_dev may still be read by the previous batch's scatter
-    HIPCHK(c, hipMemcpy(c->idx_dev, h.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    HOSTCOPY(c, c->idx_dev, h.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice);     // (the drain also ends the previous batch's scatter, which reads idx_dev)
     const int KP = c->KP;
     const int64_t Bp = round_up(n, 128);
     const int nb = c->n_cu * 8;
@@ -1736,8 +1830,8 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
     CellView& v = c->batch_view;
     v.Xgn = c->Xb_gn; v.Xng = c->Xb_ng; v.H = c->Hb; v.Y = c->Yb;
     v.N = (int)n; v.Np = Bp;
-    v.gA = make_geom(c->Gp, Bp, c->slots, 0, c->sweep_bf);
-    v.gB = make_geom(Bp, c->Gp, c->slots, 0, c->sweep_bf);
+    v.gA = make_geom(c, c->Gp, Bp, 0, c->sweep_bf);
+    v.gB = make_geom(c, Bp, c->Gp, 0, c->sweep_bf);
     if ((int64_t)v.gA.nwg * v.gA.maxp * v.gA.bf * c->KP > c->piecesA_cap || (int64_t)v.gB.nwg * v.gB.maxp * v.gB.bf * c->KP > c->piecesB_cap)
         return fail(c, ALPINE_ERR_STATE, "internal: batch view needs more sweep pieces than were allocated");
     v.statBlocks = (int)((n + HS_CELLS - 1) / HS_CELLS);
@@ -1886,7 +1980,7 @@ extern "C" int alpine_get_losses(alpine_ctx* c, double* rows, int64_t max_rows, 
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int64_t n = std::min(max_rows, c->loss_rows);
-    if (rows && n > 0) HIPCHK(c, hipMemcpy(rows, c->loss_dev, sizeof(double) * n * (c->n_cov + 2), hipMemcpyDeviceToHost));
+    if (rows && n > 0) HOSTCOPY(c, rows, c->loss_dev, sizeof(double) * n * (c->n_cov + 2), hipMemcpyDeviceToHost);
     if (n_rows) *n_rows = c->loss_rows;
     return 0;
 }
@@ -2018,6 +2112,27 @@ extern "C" int alpine_debug_set_xcd_bias(alpine_ctx* c, int per_mille)
     return 0;
 }
 
+// Diagnostics / tests: re-divide the two sweeps with teams of `width` workgroups (SweepGeom::gw; 0 = the library's own choice, 1 = no
+// teams).  Same results up to summation order; a width the grid cannot be dealt in (or a non-x3 ctx) falls back to 1.
+extern "C" int alpine_debug_set_team_width(alpine_ctx* c, int width)
+{
+    if (!c) return ALPINE_ERR_BAD_ARG;
+    if (width < 0 || width > 32) return fail(c, ALPINE_ERR_BAD_ARG, "team width %d outside [0, 32]", width);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int old = c->team_force;
+    c->team_force = width;
+    apply_sweep_geometry(c, c->sweep_bf);
+    auto need = [&](const SweepGeom& g) { return (int64_t)g.nwg * g.maxp * g.bf * c->KP; };
+    if ((!c->transform_only && need(c->geomA) > c->piecesA_cap) || need(c->geomB) > c->piecesB_cap) {
+        c->team_force = old;
+        apply_sweep_geometry(c, c->sweep_bf);
+        return fail(c, ALPINE_ERR_UNSUPPORTED, "the pieces buffers are too small for that division");
+    }
+    c->tail_valid = false;
+    return 0;
+}
+
 extern "C" int alpine_set_profiling(alpine_ctx* c, int enabled)
 {
     if (!c) return ALPINE_ERR_BAD_ARG;
@@ -2062,8 +2177,7 @@ extern "C" int alpine_read_buffer(alpine_ctx* c, int which, int64_t offset, int6
     }
     if (offset + n > size) return fail(c, ALPINE_ERR_BAD_ARG, "range outside buffer (%lld floats)", (long long)size);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(host, base + offset, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HOSTCOPY(c, host, base + offset, sizeof(float) * n, hipMemcpyDeviceToHost);
     return 0;
 }
 

@@ -132,7 +132,32 @@ struct SweepGeom {
     int dL;       // rows moved from every span of an odd workgroup to every span of an even one (multiple of SG_ROW_ALIGN, 0 = equal
                   // spans): workgroups are dispatched round-robin over the 8 XCDs and the XCDs do not stream this access pattern
                   // at the same rate; the division is static, so results never depend on where a workgroup ran
+    int gw;       // TEAM width (x3 sweeps; 1 everywhere else).  The unit of the division above is then a team of gw workgroups that
+                  // walk the SAME spans of contraction rows side by side, workgroup j of the team on columns [j, j + 1) * bf / gw of
+                  // the bf-wide tile -- bf = gw x (columns of one workgroup) -- and the gw workgroups of a team have equal
+                  // blockIdx % 8, i.e. sit on ONE XCD under the round-robin placement (sg_team_of_block): the panel rows a team
+                  // needs are fetched into that XCD's L2 once instead of gw times.  At K = 105 the panel re-reads were 27 % of the
+                  // sweep's fabric traffic with an L2 hit rate of 1.4 % (profiles/r04/cfg4_x3_share8_*): every workgroup was at a
+                  // different row of the panel at any time.  Placement only decides the speed, never the result: "workgroup" in
+                  // every comment of this division reads "team", and a piece is still bf columns x KP of one tile.
 };
+
+// blockIdx -> (team, member).  Blocks b and b + 8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md), so the gw members of a
+// team are gw consecutive blocks OF ONE XCD: b = 8 i + x  ->  team = 8 (i / gw) + x, member = i % gw.  The team's parity is the
+// XCD's parity, which is what SweepGeom::dL keys on.  A bijection of [0, 8 m gw) onto [0, 8 m) x [0, gw) (sg_grid pads the teams to
+// a multiple of 8; teams past the last span find nothing to do).
+__host__ __device__ inline void sg_team_of_block(const SweepGeom& g, int b, int& team, int& member)
+{
+    if (g.gw <= 1) { team = b; member = 0; return; }
+    const int x = b & 7, i = b >> 3;
+    team = (i / g.gw) * 8 + x;
+    member = i % g.gw;
+}
+__host__ __device__ inline int sg_grid(const SweepGeom& g)
+{
+    const int teams = (g.nwg + g.sub - 1) / g.sub;
+    return g.gw <= 1 ? teams : (teams + 7) / 8 * 8 * g.gw;
+}
 
 // span v (= piece owner) belongs to workgroup v / sub; its length is L + dL (even workgroup) or L - dL (odd workgroup); the
 // spans of workgroups 2j and 2j + 1 together cover 2 * sub * L rows of the (tile, row) space
@@ -161,10 +186,11 @@ inline int64_t sg_min64(int64_t a, int64_t b) { return a < b ? a : b; }
 // per span and tile, so the length of an accumulator chain -- and with it the rounding error of a sweep, which has the
 // same sign every iteration because X does not change -- is bounded independently of the shard size (the spans' pieces
 // are summed in float64 by the consumers).  cfg3's shares are 15 4xx-15 6xx rows: sub = 1, nothing changes there.
-inline SweepGeom sg_make_geom(int64_t F, int64_t R, int slots, int forced, int bf, int bias_pm)
+// gw > 1: `bf` is the width of a TEAM's tile (gw x the columns of one workgroup) and `slots` the number of teams.
+inline SweepGeom sg_make_geom(int64_t F, int64_t R, int slots, int forced, int bf, int bias_pm, int gw = 1)
 {
     SweepGeom g{};
-    g.F = (int)F; g.R = (int)R; g.bf = bf;
+    g.F = (int)F; g.R = (int)R; g.bf = bf; g.gw = gw;
     g.nft = (int)((F + bf - 1) / bf);
     const int64_t total = (int64_t)g.nft * R;
     int64_t want = forced > 0 ? (int64_t)g.nft * forced : slots;

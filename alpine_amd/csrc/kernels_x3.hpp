@@ -164,7 +164,9 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     SgWalk walk;
-    sg_walk_init(walk, g, blockIdx.x);
+    int team, member;
+    sg_team_of_block(g, blockIdx.x, team, member);
+    sg_walk_init(walk, g, team);
     SG_STAMP_SET(0, SG_NOW());
     unsigned long long st_flush = 0, st_first = 0, st_segs = 0;       // stamps build only
     (void)st_flush; (void)st_first; (void)st_segs;
@@ -176,7 +178,9 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
     int64_t slot;
     while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
         const int nst = (r_end - r_begin) / X3_ROWS;
-        const int f0 = (ft * 4 + wave) * WAVE_F;
+        const int wt = ft * g.gw + member;                 // this workgroup's BLOCK_F-wide tile (ft = the team's tile)
+        if ((int64_t)wt * BLOCK_F >= g.F) continue;        // a member past the last column of a partly filled team tile: nothing to do (block-uniform)
+        const int f0 = (wt * 4 + wave) * WAVE_F;
         const bool active = f0 < g.F;
         // F is a multiple of 128, not of 256: a wave whose second half lies outside re-reads its first half there (valid
         // memory; those accumulators land in piece columns >= F, which no consumer reads)
@@ -274,7 +278,7 @@ void stream_gemm_x3_kernel(const float* __restrict__ S, const float* __restrict_
         x3_stage<KT, NH, true>(acc, x, &lds[t & 1][lds_lane], xrow0, xrow1, ldS, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 = c -> f_local = WAVE_F*wave + 128*hf + 4c + t
-        float* out = pieces + (slot * BLOCK_F + wave * WAVE_F) * KP;
+        float* out = pieces + (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KP;
         const unsigned long long st_f0 = SG_NOW();
         SG_STAMP_SET(2, st_f0);
 #pragma unroll
@@ -351,7 +355,10 @@ __device__ __forceinline__ void sg_flush_tile16(float* __restrict__ tr, const f3
 // pieces keep their [.][KP] layout and every consumer is unchanged.  12.5 % fewer MFMAs at K = 105.
 // (A variant WITHOUT the zero-plane test -- on full significands it always fails, and without the branch a 64-column group
 // is one basic block for the scheduler -- was 3 % slower in A/B, cfg3 and K = 105: the test stays.)
-template <int KT, int NH, int M16A = 2 * KT>
+// ONEPLANE = true (alpine_finalize_X's census found EVERY element of X to be exactly one bf16 plane -- integer counts < 256 and the
+// like): no split and no zero-plane test, one v_cvt_pk_bf16_f32 per pair of values (exact on such data) and the three hi-plane
+// products -- the same products in the same order as the general form executes on that data, so bitwise the same pieces.
+template <int KT, int NH, int M16A = 2 * KT, bool ONEPLANE = false, bool NOTEST = false>
 __global__ __launch_bounds__(256, 1)
 void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
                             int64_t ldS, SweepGeom g, int* __restrict__ xcc_out)
@@ -375,7 +382,9 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, kg = lane >> 4;
     SgWalk walk;
-    sg_walk_init(walk, g, blockIdx.x);
+    int team, member;
+    sg_team_of_block(g, blockIdx.x, team, member);
+    sg_walk_init(walk, g, team);
 
     float pf[PVS][8];
     f32x4 x[NCG][8];
@@ -384,14 +393,22 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
     int64_t slot;
     while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
         const int nst = (r_end - r_begin) / ROWS;
-        const int f0 = (ft * 4 + wave) * WAVE_F;
+        const int wt = ft * g.gw + member;                 // this workgroup's BLOCK_F-wide tile (ft = the team's tile)
+        if ((int64_t)wt * BLOCK_F >= g.F) continue;        // a member past the last column of a partly filled team tile (block-uniform)
+        const int f0 = (wt * 4 + wave) * WAVE_F;
         const bool active = f0 < g.F;
         // F is a multiple of 128, not of 256: a wave whose second half lies outside re-reads its first half there (valid
         // memory; those accumulators are never written out)
         const bool half2 = NH == 2 && f0 + 128 < g.F;
 
         const float* pfptr = Pf + (int64_t)r_begin * KP;
+#ifdef ALPINE_DIAGNOSTICS
+        const bool pfix = g.panel_fixed == 1;          // timing-only ablation: every panel stage re-reads the span's FIRST stage (cache-resident)
+#else
+        constexpr bool pfix = false;
+#endif
         auto load_p = [&](int t) {
+            if (pfix) t = 0;
 #pragma unroll
             for (int v = 0; v < PVS; ++v) {
                 const int si = tid + NT * v;                        // set index = rb * KP + col
@@ -473,7 +490,13 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = x[cg][e][t];
                     u32x4 b[3];
-                    x3_split8_scalar(v, b);
+                    if constexpr (ONEPLANE) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b[0][q] = x3_cvt2(v[2 * q], v[2 * q + 1]);
+                        b[1] = b[2] = u32x4{0u, 0u, 0u, 0u};
+                    } else {
+                        x3_split8_scalar(v, b);
+                    }
 #pragma unroll
                     for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
@@ -482,7 +505,7 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
                                                                                          __builtin_bit_cast(bf16x8, b[0]), acc[m][4 * cg + t], 0, 0, 0);
                     // mid / lo planes of X: nothing to add when the whole 32 x 16 tile is exactly one bf16 plane (wave-uniform test)
                     const unsigned rest = (b[1][0] | b[1][1] | b[1][2] | b[1][3]) & 0x7fff7fffu;
-                    if (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
+                    if (!ONEPLANE && (NOTEST || __builtin_amdgcn_ballot_w64(rest != 0u) != 0ull)) {
 #pragma unroll
                         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
@@ -524,7 +547,7 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
         stage(&lds[t & 1][lds_lane], 0, true);
 
         // D: component = 16 m + 4 kg + e, column = c16 -> f_local = WAVE_F * wave + 64 cg + 4 c16 + t
-        float* out = pieces + (slot * BLOCK_F + wave * WAVE_F) * KP;
+        float* out = pieces + (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KP;
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
             if (cg >= 2 && !half2) break;                  // second half outside F: nothing to write

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALPINE_HIP_ABI_VERSION 5
+#define ALPINE_HIP_ABI_VERSION 6
 
 typedef struct alpine_ctx alpine_ctx;
 
@@ -125,6 +125,8 @@ typedef struct {
     int32_t spans_per_workgroup_a, spans_per_workgroup_b;  /* accumulator restarts + 1 of a sweep workgroup (1 at BASELINE config 3) */
     int32_t xcd_bias_per_mille;     /* spans of even sweep workgroups are this much longer (negative: shorter) than the mean, odd ones the opposite */
     int32_t xcc_of_workgroup0;      /* placement probe: XCC id workgroup 0 of a one-per-CU grid landed on (-1: not probed) */
+    int32_t team_width_a, team_width_b;   /* x3 sweeps: workgroups of one XCD that walk the same contraction rows side by side and share the
+                                             panel through that XCD's L2 (1 = none); grid_a / grid_b count workgroups, not teams */
 } alpine_info;
 
 /* Number of floats in the per-iteration reduce block for a configuration (so a caller can allocate
@@ -195,6 +197,13 @@ int alpine_comm_get_unique_id(void* id_out /* ALPINE_COMM_ID_BYTES bytes */);
 int alpine_comm_init_rank(alpine_ctx* ctx, const void* id, int nranks, int rank);
 /* ncclGetVersion of the librccl this library is linked against, as one integer (e.g. 22203); for run reports. */
 int alpine_comm_version(int* version_out);
+/* Rank count and this ctx's rank as the ATTACHED communicator reports them (ncclCommCount / ncclCommUserRank), for run reports that
+ * must show RCCL saw N ranks; ALPINE_ERR_STATE without a communicator.  Either pointer may be NULL. */
+int alpine_comm_count(alpine_ctx* ctx, int* nranks_out, int* rank_out);
+/* ONE process, n ctxs on n DIFFERENT GPUs (the reference's fit is one blocking call in one process, main.py:82-147): ncclCommInitAll
+ * over the ctxs' devices, ctxs[i] becomes rank i.  No unique id, no launcher.  Afterwards each ctx is driven by its own host thread
+ * (a ctx stays single-threaded): the composite entry points called concurrently on the n ctxs meet inside the all-reduce. */
+int alpine_comm_init_all(alpine_ctx* const* ctxs, int n);
 int alpine_comm_destroy(alpine_ctx* ctx);
 int alpine_comm_all_reduce(alpine_ctx* ctx, int64_t offset_floats, int64_t n_floats);
 /* alpine_iter_begin + [all-reduce when a communicator is attached] + alpine_iter_end(update). */
@@ -249,6 +258,9 @@ enum { ALPINE_KERNEL_SWEEP_XHT = 0, ALPINE_KERNEL_SWEEP_WTX = 1, ALPINE_KERNEL_A
 int alpine_set_profiling(alpine_ctx* ctx, int enabled);
 /* Diagnostics: span length of even sweep workgroups +per_mille, odd -per_mille (same results up to summation order). */
 int alpine_debug_set_xcd_bias(alpine_ctx* ctx, int per_mille);
+/* Diagnostics / tests: teams of `width` sweep workgroups (alpine_info.team_width_*): 0 = the library's own choice, 1 = none.  Same
+ * results up to summation order. */
+int alpine_debug_set_team_width(alpine_ctx* ctx, int width);
 /* Diagnostics: 2 * n_pairs steady-state MU iterations (no loss rows, no communicator) replayed from a hipGraph of two. */
 int alpine_debug_run_graph(alpine_ctx* ctx, int n_pairs);
 int alpine_get_kernel_time(alpine_ctx* ctx, int which, double* total_ms, int64_t* launches);

@@ -832,6 +832,22 @@ def test_fit_uploads_X_once_and_keeps_it_for_compute_loss_and_transform(monkeypa
     m3.transform(MiniAnnData(c.X.copy(), c.obs.copy()), n_iter=2)
     assert len(uploads) == before + 1 and m3._resident is None
     m3.release()
+    # in-place PERMUTATIONS keep every value (and every per-block sum): a row swap and a shuffle must force a re-upload too
+    for edit in ("swap", "shuffle"):
+        ad4 = MiniAnnData(c.X.copy(), c.obs.copy())
+        m4 = ALPINE(device="cuda:0", keep_resident=True, **c.params).fit(ad4, covariate_keys=c.keys, max_iter=3)
+        assert m4._resident is not None
+        if edit == "swap":
+            ad4.X[[0, 1]] = ad4.X[[1, 0]]
+        else:
+            np.random.default_rng(5).shuffle(ad4.X)
+        before = len(uploads)
+        loss4 = m4.compute_loss(ad4)
+        assert len(uploads) == before + 1 and m4._resident is None, edit
+        ad5 = MiniAnnData(ad4.X.copy(), c.obs.copy())
+        ad5.obsm.update(ad4.obsm)
+        ad5.varm.update(ad4.varm)
+        assert abs(loss4 - m4.compute_loss(ad5)) <= 1e-6 * abs(loss4)
 
 
 def test_trace_form_loss_cancellation_bound_on_a_near_exact_fit():
@@ -921,3 +937,80 @@ def test_placement_probe_and_graph_replay_are_result_neutral():
     assert np.array_equal(W1, W2) and np.array_equal(H1, H2)
     for a, b in zip(B1, B2):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ round 4: teams of sweep workgroups, one-plane form of the K > 64 sweeps
+@pytest.mark.parametrize("name", ["counts_2cov", "mid_counts", "k74", "k105", "guided_wide", "kl_2cov_nan", "wide_k150"])
+def test_x3_teams_agree_with_the_reference(name):
+    """SweepGeom::gw: teams of 2 / 4 / 8 sweep workgroups walk the same contraction rows side by side (one XCD, shared panel).  A division like any
+    other -- results differ from the team-less one in summation order only -- so every width must meet the reference tolerances, on both tile
+    widths' worth of shapes (all golden cases are small: most team members of the last tile have no columns, which is the edge to cover),
+    on the blocked K > 128 path too."""
+    c = load_case(name)
+    res = {}
+    for width in (1, 2, 4, 8):
+        eng = make_engine(c, x_dtype="x3")
+        eng.debug_set_team_width(width)
+        info = eng.info()
+        assert info.team_width_a == width and info.team_width_b == width, (width, info.team_width_a, info.team_width_b)
+        assert info.grid_a % (8 * width) == 0 or width == 1
+        eng.run(c.T, with_loss=True)
+        res[width] = (eng.get_factors(), eng.losses())
+        eng.close()
+        W, H, Bs = res[width][0]
+        assert rel_fro(W, c.WT_unscaled) < 1e-4 and rel_fro(H, c.HT_unscaled) < 1e-4, (name, width)
+        assert_loss_rows_close(res[width][1], c.loss_history, n_cells=c.X.shape[0])
+    for width in (2, 4, 8):
+        assert rel_fro(res[width][0][0], res[1][0][0]) < 2e-5 and rel_fro(res[width][0][1], res[1][0][1]) < 2e-5, (name, width)
+
+
+def test_team_width_is_chosen_from_the_shape_and_the_data():
+    """The library's own choice (alpine_info.team_width_*): the widest of 8 / 4 / 2 that leaves at most 2.5 % of the members idle, 1 where
+    teams do not pay (K <= 64 on data with full significands), never for forced divisions or the float32-MFMA sweeps."""
+    nat = _native()
+    def widths(G, N, K, x_dtype="x3", fullsig=False, **kw):
+        rng = np.random.default_rng(0)
+        X = rng.gamma(0.3, 3.0, size=(N, G)).astype(np.float32) if fullsig else rng.poisson(1.0, size=(N, G)).astype(np.float32)
+        eng = nat.NativeShard(n_genes=G, n_cells=N, n_components=K, cov_components=[], cov_levels=[], lam=[], x_dtype=x_dtype, **kw)
+        eng.upload_X_host(X)
+        eng.finalize_X()
+        info = eng.info()
+        eng.close()
+        return info.team_width_a, info.team_width_b
+    # 4096 genes = 8 tiles of 512 -> 8; 70 000 cells -> 69 tiles of 1024 (K <= 64, > 65 536 cells) -> 72 with 8 (4 % idle) no, 4 (72: no) -> 2 (70: 1.4 %)
+    assert widths(4096, 2048, 20) == (8, 4)                       # narrow tiles (small shard): 8 of 8, 4 of 4
+    assert widths(4096, 2048, 20, fullsig=True) == (1, 1)         # K <= 64 on full significands: no teams
+    assert widths(4096, 2048, 100, fullsig=True) == (8, 4)        # K > 64: teams whatever the data
+    assert widths(4096, 2048, 20, x_dtype="f32") == (1, 1)
+    assert widths(4096, 2048, 20, split_a=2, split_b=2) == (1, 1)
+
+
+@pytest.mark.parametrize("name,K", [("k105", None), ("k74", None), ("guided_wide", None)])
+def test_one_plane_form_of_the_wide_sweeps_is_bitwise_the_general_form(name, K, monkeypatch):
+    """K > 64 on X whose every element is exactly one bf16 plane (integer counts < 256: alpine_finalize_X's census): the sweeps run
+    stream_gemm_x3w_kernel's one-plane form (no split, no zero-plane test).  Same products in the same order as the general form executes on
+    such data: the two must agree BITWISE (the general form is selected with ALPINE_HIP_X3_VARIANT=2), and a single element with a second
+    plane must switch the census back."""
+    c = _count_like(load_case(name), 6.0)
+    assert float(c.X.max()) < 256
+    a = make_engine(c, x_dtype="x3")
+    assert a.info().x_multi_plane_fraction == 0.0 and a.info().x3_wide == 1
+    monkeypatch.setenv("ALPINE_HIP_X3_VARIANT", "2")
+    b = make_engine(c, x_dtype="x3")
+    monkeypatch.delenv("ALPINE_HIP_X3_VARIANT")
+    for e in (a, b):
+        e.run(4, with_loss=True)
+    (Wa, Ha, Ba), (Wb, Hb, Bb) = a.get_factors(), b.get_factors()
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb) and np.array_equal(a.losses(), b.losses())
+    a.close()
+    b.close()
+    c.X = c.X.copy()
+    c.X[3, 5] = 257.0                                   # two planes
+    d = make_engine(c, x_dtype="x3")
+    assert d.info().x_multi_plane_fraction > 0
+    d.run(2, with_loss=True)
+    f = make_engine(c)                                  # float32 MFMA on the same data
+    f.run(2, with_loss=True)
+    assert rel_fro(d.get_factors()[0], f.get_factors()[0]) < 2e-5
+    d.close()
+    f.close()

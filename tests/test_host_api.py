@@ -356,3 +356,39 @@ def test_replay_randperms_leaves_the_generator_where_torch_randperm_does(n, time
         replay_randperms(n, times)
         assert torch.equal(torch.get_rng_state(), want_state)
         assert torch.equal(torch.rand(7), want_next)
+
+
+def test_x_fingerprint_sees_value_edits_and_permutations(monkeypatch):
+    """The digest behind keep_resident (ALPINE._x_fingerprint) must change under ANY in-place edit of X -- a value, a row swap, a shuffle
+    (the per-block sums of round 3 could not see the last two: ADVICE r3) -- on C- and F-ordered inputs, with xxhash and with the zlib
+    fall-back, and must not change when nothing did."""
+    import builtins
+    from alpine_amd.model import ALPINE
+    rng = np.random.default_rng(0)
+    real_import = builtins.__import__
+
+    def without_xxhash(name, *a, **kw):
+        if name == "xxhash":
+            raise ImportError("hidden by the test")
+        return real_import(name, *a, **kw)
+
+    for hide in (False, True):
+        if hide:
+            monkeypatch.setattr(builtins, "__import__", without_xxhash)
+        for order in ("C", "F"):
+            X = np.asarray(rng.poisson(1.0, size=(500, 300)).astype(np.float32), order=order)
+            base = ALPINE._x_fingerprint(X)
+            assert ALPINE._x_fingerprint(X) == base
+            Y = X.copy(order=order)
+            assert ALPINE._x_fingerprint(Y)[1:] == base[1:]                 # same bytes, another buffer: only the address differs
+            X[[0, 1]] = X[[1, 0]]
+            assert (X[0] != X[1]).any() and ALPINE._x_fingerprint(X) != base, (hide, order, "row swap")
+            X[[0, 1]] = X[[1, 0]]
+            assert ALPINE._x_fingerprint(X) == base
+            rng.shuffle(X)
+            assert ALPINE._x_fingerprint(X) != base, (hide, order, "shuffle")
+            X[:] = Y
+            assert ALPINE._x_fingerprint(X) == base
+            X[7, 11] = np.nextafter(X[7, 11], np.float32(np.inf))           # one ulp in one element
+            assert ALPINE._x_fingerprint(X) != base, (hide, order, "one ulp")
+    monkeypatch.undo()

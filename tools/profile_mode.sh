@@ -35,6 +35,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/write" --
 echo "WRITE_SIZE pass done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$RAW/sq" -- python3 "$ROOT/bench.py" $COMMON --steps 3 --warmup 1 > /dev/null 2> "$RAW/sq.err"
 echo "SQ pass done"
+# L2 hit rate of the sweep (panel re-reads that stay inside the XCD vs cross the fabric); optional: a refused counter name must not lose the other passes
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$RAW/tcc" -- python3 "$ROOT/bench.py" $COMMON --steps 3 --warmup 1 > /dev/null 2> "$RAW/tcc.err" && echo "TCC pass done" || echo "TCC pass failed (ignored)"
 cd "$ROOT"
 python3 tools/summarize_pmc.py "$RAW" "$OUT" "$WL" "$MT"
 rm -rf "$RAW"

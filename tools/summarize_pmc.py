@@ -39,8 +39,10 @@ def main():
     stats = glob.glob(os.path.join(raw, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(out, f"{wl}_{mode}_kernel_stats.csv"))
-    groups = {g: counter_means(os.path.join(raw, g)) for g in ("fetch", "write", "sq")}
+    groups = {g: counter_means(os.path.join(raw, g)) for g in ("fetch", "write", "sq", "tcc")}
     for g, means in groups.items():
+        if g == "tcc" and not means:
+            continue
         write_means(os.path.join(out, f"{wl}_{mode}_pmc_{g}.csv"), means)
     sweep = [k for (k, c) in groups["fetch"] if "stream_gemm" in k]
     if not sweep:
@@ -76,6 +78,10 @@ def main():
                     summary["avg_launch_ms_kernel_trace"] = float(row["AverageNs"]) / 1e6
                     summary["kernel_trace_calls"] = int(row["Calls"])
                     break
+    hit = groups["tcc"].get((k, "TCC_HIT_sum"), (None, 0))[0]
+    miss = groups["tcc"].get((k, "TCC_MISS_sum"), (None, 0))[0]
+    if hit is not None and miss is not None and hit + miss > 0:
+        summary["TCC_HIT_sum"], summary["TCC_MISS_sum"], summary["l2_hit_rate"] = hit, miss, hit / (hit + miss)
     tag = "" if mode == "f32" else f"_{mode}"
     if stats and summary["avg_launch_ms_kernel_trace"] and gui:
         # DVFS note of MI355X_MICROARCH.md: effective shader clock ~ GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time
