@@ -31,7 +31,7 @@ EXPORTS = [
     "alpine_als_begin", "alpine_als_group_begin", "alpine_als_group_end", "alpine_reduce_block_hht", "alpine_batch_step", "alpine_batch_begin", "alpine_batch_end", "alpine_epoch_loss", "alpine_epoch_loss_begin", "alpine_epoch_loss_end", "alpine_run", "alpine_transform", "alpine_get_losses", "alpine_reset_losses", "alpine_scale", "alpine_synchronize",
     "alpine_eval_recon_direct", "alpine_set_profiling", "alpine_debug_set_xcd_bias", "alpine_debug_run_graph", "alpine_get_kernel_time", "alpine_read_buffer",
     "alpine_comm_get_unique_id", "alpine_comm_version", "alpine_comm_init_rank", "alpine_comm_destroy", "alpine_comm_all_reduce", "alpine_iter",
-    "alpine_comm_count", "alpine_comm_init_all", "alpine_debug_set_team_width",
+    "alpine_comm_count", "alpine_comm_init_all", "alpine_debug_set_team_width", "alpine_debug_set_option",
 ]
 ABI_VERSION = 6          # ALPINE_HIP_ABI_VERSION of include/alpine_hip.h this binding was written against
 
@@ -130,6 +130,7 @@ def load() -> C.CDLL:
     lib.alpine_comm_count.argtypes = [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.alpine_comm_init_all.argtypes = [C.POINTER(p), i32]
     lib.alpine_debug_set_team_width.argtypes = [p, i32]
+    lib.alpine_debug_set_option.argtypes = [p, C.c_char_p, i32]
     for name in EXPORTS:
         if name not in ("alpine_reduce_block_floats", "alpine_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -181,6 +182,11 @@ class NativeShard:
             msg = self._lib.alpine_last_error(None).decode()
             self._h = C.c_void_p()
             raise AlpineNativeError(rc, msg)
+        try:
+            self.info()                      # ABI version of the loaded library against this binding (a stale build, ALPINE_HIP_LIBRARY)
+        except AlpineNativeError:
+            self.close()
+            raise
 
     # -- plumbing
     def _chk(self, rc: int):
@@ -354,6 +360,11 @@ class NativeShard:
 
     def debug_set_xcd_bias(self, per_mille: int):
         self._chk(self._lib.alpine_debug_set_xcd_bias(self._h, int(per_mille)))
+
+    def debug_set_option(self, name: str, value: int):
+        """Result-preserving knobs (tests, tools): 'no_tail', 'fused_w', 'unfused_mid', 'guided_scalar', 'tail_stats_per_covariate',
+        'sg_variant'; before finalize_X: 'x3_variant' (-1 | 0 | 2), 'x3_narrow' (0 | 1).  The library takes none of them from the environment."""
+        self._chk(self._lib.alpine_debug_set_option(self._h, name.encode(), int(value)))
 
     def debug_set_team_width(self, width: int):
         self._chk(self._lib.alpine_debug_set_team_width(self._h, int(width)))

@@ -133,12 +133,12 @@ struct alpine_ctx {
     int* xcc_dev = nullptr;           // ... written here by that launch
     bool probe_placement = false;
     int xcd_bias_pm = 0;              // env ALPINE_HIP_XCD_BIAS (per mille): span length of even workgroups +bias, odd -bias (see SweepGeom::dL)
-    bool h_update_valu = false;       // env ALPINE_HIP_H_UPDATE=valu: lane-broadcast VALU form of the H update instead of MFMA
     int sg_variant = 0;               // env ALPINE_HIP_SG_VARIANT: pipeline shape of the sweep kernel (A/B experiments)
     int x3_variant = -1;              // env ALPINE_HIP_X3_VARIANT: 0 = 32x32x16 MFMA, 2 = 16x16x32 (x3w), unset = chosen from the data
     bool x3_wide = false;             // the sweeps use stream_gemm_x3w_kernel (decided in alpine_finalize_X)
     bool x3_narrow = false;           // 512-column workgroup tiles at K <= 64 (in effect)
     bool x3_narrow_pref = false;      // ... wanted for this shard size; alpine_finalize_X confirms it once the matrix instruction is known
+    bool x3_narrow_forced = false;    // ... asked for explicitly (alpine_debug_set_option "x3_narrow"): kept whatever the matrix instruction
     double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
     bool x_one_plane = false;         // ... and NONE is (census of alpine_finalize_X): the K > 64 sweeps then run the form without split and zero-plane test
     bool team_ok = true;              // teams pay for this ctx's data and model size (decided in alpine_finalize_X; see team_width)
@@ -214,7 +214,17 @@ static int host_copy_2d(alpine_ctx* c, void* dst, size_t dpitch, const void* src
     }
 
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-static bool getenv_is(const char* name, char v) { const char* e = std::getenv(name); return e && e[0] == v; }
+// Environment variables.  The PRODUCTION library reads three, all at alpine_create / load time: ALPINE_HIP_GUARD (diagnostics allocator),
+// ALPINE_HIP_LDS_LIMIT (lowers the LDS budget of the H update's optional parts: exercises its fall-backs) and ALPINE_HIP_XCD_BIAS
+// (0 = equal spans = the bit-reproducible setting, see alpine_finalize_X).  Every knob that switches a kernel or a launch structure
+// is an explicit call, alpine_debug_set_option(ctx, name, value) -- a stray variable in a user's environment cannot change which
+// kernel runs.  Only the diagnostics build (-DALPINE_DIAGNOSTICS, tools/) also takes them from ALPINE_HIP_<NAME> variables.
+#ifdef ALPINE_DIAGNOSTICS
+static const char* knob_env(const char* name) { return std::getenv(name); }
+#else
+static const char* knob_env(const char*) { return nullptr; }
+#endif
+static bool knob_is(const char* name, char v) { const char* e = knob_env(name); return e && e[0] == v; }
 
 // Diagnostics, ALPINE_HIP_GUARD=1: a device-side write past either end of a buffer does not fault when the neighbouring addresses are
 // mapped (another buffer, or host memory the runtime keeps pinned) -- it corrupts silently.  In guard mode every buffer is allocated with
@@ -383,6 +393,10 @@ static SweepGeom make_geom(const alpine_ctx* c, int64_t F, int64_t R, int forced
 {
     if (gw <= 0) gw = team_width(c, F, bf_wg, forced);
     else if (!c->x3 || forced > 0 || c->slots % (8 * gw) != 0) gw = 1;
+    // K > 64 in teams: the even/odd bias the placement probe chose for the team-less division costs 2 % there (tools/team_ab.py, one
+    // engine, interleaved: K = 105 at 125 000 cells 3.630 ms per iteration with -40 per mille, 3.547 without; at K = 60 the bias still
+    // pays with teams: 5.284 vs 5.340 ms) -- an explicitly requested bias (environment, alpine_debug_set_xcd_bias) is left alone
+    if (gw > 1 && c->KT >= 3 && c->xcd_bias_auto) bias_pm = 0;
     return sg_make_geom(F, R, std::max(1, c->slots / gw), forced, bf_wg * gw, bias_pm, gw);
 }
 
@@ -415,21 +429,18 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         c->lds_dev = c->lds_max;
         if (const char* e = std::getenv("ALPINE_HIP_LDS_LIMIT")) { const long v = std::atol(e); if (v > 0 && (size_t)v < c->lds_max) c->lds_max = (size_t)v; }   // tests: exercise the fall-backs
     }
-    c->unfused_mid = getenv_is("ALPINE_HIP_UNFUSED_MID", '1');
-    c->no_tail = getenv_is("ALPINE_HIP_NO_TAIL", '1') || c->unfused_mid;
-    c->fused_w = !getenv_is("ALPINE_HIP_FUSED_W", '0') && !c->unfused_mid;
-#ifdef ALPINE_DIAGNOSTICS
-    c->ablate_stride0 = getenv_is("ALPINE_HIP_ABLATE_STRIDE0", '1');
-    c->ablate_panel = getenv_is("ALPINE_HIP_ABLATE_PANEL", '1');
-    c->ablate_flush = getenv_is("ALPINE_HIP_ABLATE_FLUSH", '1');
-    if (const char* e = std::getenv("ALPINE_HIP_X3_ABLATE")) c->x3_ablate = std::atoi(e);
-#endif
-    c->tail_stats_per_cov = getenv_is("ALPINE_HIP_TAIL_STATS", 'p');
-    if (const char* e = std::getenv("ALPINE_HIP_GUIDED")) c->no_guided_mfma = (std::strcmp(e, "scalar") == 0);
+    c->unfused_mid = knob_is("ALPINE_HIP_UNFUSED_MID", '1');
+    c->no_tail = knob_is("ALPINE_HIP_NO_TAIL", '1') || c->unfused_mid;
+    c->fused_w = !knob_is("ALPINE_HIP_FUSED_W", '0') && !c->unfused_mid;
+    c->ablate_stride0 = knob_is("ALPINE_HIP_ABLATE_STRIDE0", '1');
+    c->ablate_panel = knob_is("ALPINE_HIP_ABLATE_PANEL", '1');
+    c->ablate_flush = knob_is("ALPINE_HIP_ABLATE_FLUSH", '1');
+    if (const char* e = knob_env("ALPINE_HIP_X3_ABLATE")) c->x3_ablate = std::atoi(e);
+    c->tail_stats_per_cov = knob_is("ALPINE_HIP_TAIL_STATS", 'p');
+    if (const char* e = knob_env("ALPINE_HIP_GUIDED")) c->no_guided_mfma = (std::strcmp(e, "scalar") == 0);
     if (const char* e = std::getenv("ALPINE_HIP_XCD_BIAS")) { c->xcd_bias_pm = std::max(-200, std::min(200, std::atoi(e))); c->xcd_bias_auto = false; }
-    if (const char* e = std::getenv("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
-    if (const char* e = std::getenv("ALPINE_HIP_X3_VARIANT")) c->x3_variant = std::atoi(e);
-    if (const char* e = std::getenv("ALPINE_HIP_H_UPDATE")) c->h_update_valu = (std::strcmp(e, "valu") == 0);
+    if (const char* e = knob_env("ALPINE_HIP_SG_VARIANT")) c->sg_variant = std::atoi(e);
+    if (const char* e = knob_env("ALPINE_HIP_X3_VARIANT")) c->x3_variant = std::atoi(e);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
 
@@ -466,11 +477,11 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     const int64_t Gp = c->Gp, Np = c->Np; const int KP = c->KP;
     // sweeps
     // bf16 sweeps with K <= 64: 8-wave workgroups (1024-column tiles, one per CU); everything else 4 waves x 512 columns
-    c->sweep_waves = (c->bf16 && c->KT <= 2 && !getenv_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;   // A/B of the workgroup shape, same results
+    c->sweep_waves = (c->bf16 && c->KT <= 2 && !knob_is("ALPINE_HIP_BF16_WAVES", '4')) ? 8 : 4;   // (diagnostics build: A/B of the workgroup shape, same results)
     int slots = c->n_cu * (c->KT <= 2 && c->sweep_waves == 4 && !c->x3 ? 2 : 1);   // resident workgroups: x3 and 8-wave bf16 run one per CU
     // experiment knob (same results): K <= 32 x3 kernels fit two waves per SIMD (<= 256 registers): ALPINE_HIP_X3_SLOTS=2 gives them
     // two workgroups per CU -- the one data point available for "would a second wave per SIMD help the memory-bound sweep?"
-    if (c->x3 && c->KT == 1 && getenv_is("ALPINE_HIP_X3_SLOTS", '2')) slots = 2 * c->n_cu;
+    if (c->x3 && c->KT == 1 && knob_is("ALPINE_HIP_X3_SLOTS", '2')) slots = 2 * c->n_cu;
     c->slots = slots;
     // K <= 64: 1024-column workgroup tiles (a wave owns 256 columns) -- except for small shards on the 32x32x16 form, where the
     // piece traffic (every workgroup flushes bf x KP accumulators whatever the shard size: 67 MB per sweep at 1024 columns,
@@ -478,7 +489,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     // 1024 columns: 25 000 cells 0.7436 vs 0.7510, 50 000 cells 1.360 vs 1.399, 100 000 cells 2.680 vs 2.640, 200 000 cells
     // +0.8 %; on the 16x16x32 form (x3w) 512 columns LOSE at 25 000 cells (0.794 vs 0.779).  So: 512 columns for shards of
     // <= 65 536 cells unless alpine_finalize_X selects x3w.  ALPINE_HIP_X3_NARROW=0|1 forces one form.
-    if (const char* e = std::getenv("ALPINE_HIP_X3_NARROW")) c->x3_narrow_pref = (e[0] == '1');
+    if (const char* e = knob_env("ALPINE_HIP_X3_NARROW")) { c->x3_narrow_pref = (e[0] == '1'); c->x3_narrow_forced = true; }
     else c->x3_narrow_pref = cfg->n_cells <= 65536;
     if (c->x3_ablate || !c->x3 || c->KT > 2) c->x3_narrow_pref = false;   // (the diagnostics build's ablated kernels are 1024-column only)
     c->batch_cap = cfg->batch_capacity;
@@ -508,7 +519,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     };
     const int bf_default = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
     piece_floats(bf_default, &c->piecesA_cap, &c->piecesB_cap);
-    if (c->x3_narrow_pref) piece_floats(512, &c->piecesA_cap, &c->piecesB_cap);
+    if (c->x3 && c->KT <= 2 && !c->x3_ablate) piece_floats(512, &c->piecesA_cap, &c->piecesB_cap);     // (alpine_debug_set_option "x3_narrow" may ask for it later)
     c->x3_narrow = c->x3_narrow_pref;                 // until alpine_finalize_X knows the data
     apply_sweep_geometry(c, c->x3_narrow ? 512 : bf_default);
 
@@ -830,7 +841,7 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         if (c->x3 && team_ok != c->team_ok) { c->team_ok = team_ok; apply_sweep_geometry(c, c->sweep_bf); c->tail_valid = false; }
         if (c->x3 && c->KT <= 2) {
             // tile width (see alpine_create): 512 columns only for small shards on the 32x32x16 form
-            const bool narrow = c->x3_narrow_pref && (!c->x3_wide || std::getenv("ALPINE_HIP_X3_NARROW") != nullptr);
+            const bool narrow = c->x3_narrow_pref && (!c->x3_wide || c->x3_narrow_forced);
             if (narrow != c->x3_narrow) { c->x3_narrow = narrow; apply_sweep_geometry(c, narrow ? 512 : 1024); c->tail_valid = false; }
         }
     }
@@ -844,13 +855,17 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         // (still zero) panel reports where its workgroup 0 ran.  The division itself stays a static function of blockIdx:
         // results never depend on placement, only this 1 % does.
         c->probe_placement = true;
+        HIPCHK(c, hipMemsetAsync(c->xcc_dev, 0xff, sizeof(int) * 2, c->stream));        // -1: "no report" (a one-workgroup grid has no workgroup 1)
         rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB, 1);
         c->probe_placement = false;
         if (rc) return rc;
-        int h = -1;
-        HOSTCOPY(c, &h, c->xcc_dev, sizeof(int), hipMemcpyDeviceToHost);
+        int hh[2] = {-1, -1};
+        HOSTCOPY(c, hh, c->xcc_dev, sizeof hh, hipMemcpyDeviceToHost);
+        const int h = hh[0];
         c->xcc_of_wg0 = h;
-        const int bias = h < 0 ? 0 : ((h & 1) ? -XCD_BIAS_MAG : XCD_BIAS_MAG);      // workgroup 0 on an odd XCC: the even workgroups are the slow ones
+        // workgroup 0 on an odd XCC: the even workgroups are the slow ones.  No bias unless workgroup 1 sits on an XCC of the OTHER parity
+        // (a partitioned device with every workgroup on one XCC, a one-workgroup grid): the even/odd split would only unbalance the grid.
+        const int bias = (h < 0 || hh[1] < 0 || ((h ^ hh[1]) & 1) == 0) ? 0 : ((h & 1) ? -XCD_BIAS_MAG : XCD_BIAS_MAG);
         if (bias != c->xcd_bias_pm) {
             const int old_bias = c->xcd_bias_pm;
             c->xcd_bias_pm = bias;
@@ -1191,12 +1206,7 @@ static int launch_w_update(alpine_ctx* c, const float* HHt, bool update, int k_l
 {
     const int KP = c->KP;
     const float l2 = (float)((1.0 - c->l1r) * c->alpha), l1 = (float)(c->l1r * c->alpha);
-    // dotpart has one float64 partial per wave of the VALU form (8 genes per wave); the MFMA form fills fewer
-    if (c->h_update_valu) {
-        DISPATCH_KT(c->KT, hipLaunchKernelGGL(w_update_kernel<KT_>, dim3(c->ndot / 4), dim3(256), sizeof(float) * KP * KP, c->stream, c->W, c->red,
-                                               HHt, c->dotpart, c->G, c->K, (float)c->orth, l2, l1, (float)c->eps, update ? 1 : 0, k_lo, k_hi,
-                                               block_orth ? 1 : 0));
-    } else {
+    {
         // 32 genes per wave: ceil(G/128) blocks; the remaining dotpart entries stay at their initial zero
         const size_t bytes = sizeof(float) * (KP * KP + 4 * 32 * (KP + 4));          // M + the waves' row-major tiles
         if (bytes > c->lds_dev) return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the W update needs %zu bytes of LDS, the device has %zu", bytes, c->lds_dev);
@@ -1220,15 +1230,8 @@ static void cov_maxima(const alpine_ctx* c, int* max_k, int* max_ct)
 static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi, int only_cov, bool with_tail = false)
 {
     const int KP = c->KP, K = c->K;
-    const size_t h_bytes = sizeof(float) * (KP * KP + std::max(1, c->nB));
     size_t h_bytes_mfma = sizeof(float) * (KP * KP + ((std::max(1, c->nB) + 3) & ~3) + 4 * 32 * (KP + 4));   // + per-wave transpose scratch
-    int guided_total = 0;
-    for (int i = 0; i < c->n_cov; ++i) guided_total += c->cov_k[i];
-    if (c->h_update_valu && !c->use_als && guided_total <= 64) {   // the same update on the VALU (A/B; its guided columns must sit in lanes 0..63)
-        const int hblocks = (int)((v.N + UPD_ROWS * 4 - 1) / (UPD_ROWS * 4));
-        DISPATCH_KT(c->KT, hipLaunchKernelGGL(h_update_kernel<KT_>, dim3(hblocks), dim3(256), h_bytes, c->stream, v.H, c->piecesB, v.gB,
-                                               c->WtW, v.Y, c->B[c->bcur], c->meta, v.N, v.Np, K, (float)c->eps, c->nB));
-    } else {
+    {
         HTail tail{};
         const int hblocks = (int)((v.N + 127) / 128);
         // Optional LDS on top of the update's own (2 W^T W, B, the waves' tiles: ~134 KB at K > 96): the Y copy of the block's
@@ -1282,7 +1285,7 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
         }
     }
     HIPCHK(c, hipGetLastError());
-    c->tail_valid = with_tail && !(c->h_update_valu && !c->use_als && guided_total <= 64);
+    c->tail_valid = with_tail;
     return 0;
 }
 
@@ -1329,7 +1332,7 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
     const int KP = c->KP, K = c->K;
     const float* HHt = c->red + c->red_hht;
     const bool mu = update && !c->use_als;
-    const bool fused_w = mu && c->fused_w && !c->h_update_valu;
+    const bool fused_w = mu && c->fused_w;
     // MU: this launch also updates W (and, fused, emits the partial blocks of W_new^T W_new); block-coordinate: dot partials
     // only (the group loop below updates W)
     if ((rc = launch_w_update(c, HHt, mu, 0, K, false, fused_w ? c->gramPart : nullptr))) return rc;
@@ -1710,14 +1713,18 @@ extern "C" int alpine_comm_init_all(alpine_ctx* const* ctxs, int n)
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i]) return fail(nullptr, ALPINE_ERR_BAD_ARG, "alpine_comm_init_all: ctxs[%d] is NULL", i);
         if (ctxs[i]->comm) return fail(ctxs[i], ALPINE_ERR_STATE, "the ctx already has a communicator");
-        for (int j = 0; j < i; ++j)
-            if (ctxs[j]->device == ctxs[i]->device)
-                return fail(ctxs[i], ALPINE_ERR_BAD_ARG, "alpine_comm_init_all: ctxs %d and %d share device %d (RCCL needs one GPU per rank)", j, i, ctxs[i]->device);
     }
+    // (two ctxs on one device: RCCL itself refuses that -- its error text comes back through ALPINE_ERR_RCCL)
     std::vector<int> devs(n);
     std::vector<ncclComm_t> comms(n, nullptr);
     for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-    NCCLCHK(ctxs[0], ncclCommInitAll(comms.data(), n, devs.data()));
+    {
+        const ncclResult_t r = ncclCommInitAll(comms.data(), n, devs.data());
+        if (r != ncclSuccess) {
+            for (int i = 0; i < n; ++i) fail(ctxs[i], ALPINE_ERR_RCCL, "ncclCommInitAll over %d device(s) failed: %s", n, ncclGetErrorString(r));
+            return fail(nullptr, ALPINE_ERR_RCCL, "ncclCommInitAll over %d device(s) failed: %s", n, ncclGetErrorString(r));
+        }
+    }
     for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[i]; ctxs[i]->comm_ranks = n; ctxs[i]->comm_rank = i; }
     return 0;
 }
@@ -2100,14 +2107,53 @@ extern "C" int alpine_debug_set_xcd_bias(alpine_ctx* c, int per_mille)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int old = c->xcd_bias_pm;
+    const bool old_auto = c->xcd_bias_auto;
     c->xcd_bias_pm = std::max(-200, std::min(200, per_mille));
+    c->xcd_bias_auto = false;                          // an explicit request: applied as given (make_geom)
     apply_sweep_geometry(c, c->sweep_bf);
     auto need = [&](const SweepGeom& g) { return (int64_t)g.nwg * g.maxp * g.bf * c->KP; };
     if (need(c->geomA) > c->piecesA_cap || need(c->geomB) > c->piecesB_cap) {
         c->xcd_bias_pm = old;
+        c->xcd_bias_auto = old_auto;
         apply_sweep_geometry(c, c->sweep_bf);
         return fail(c, ALPINE_ERR_UNSUPPORTED, "the pieces buffers are too small for that division");
     }
+    c->tail_valid = false;
+    return 0;
+}
+
+// Diagnostics / tests: the result-preserving knobs of the library (same factors up to summation order, different kernels or launch
+// structure), one explicit call each -- the production library takes none of them from the environment.
+//   "no_tail" 0|1        separate phase1_open_kernel every iteration instead of the H update's fused tail
+//   "fused_w" 0|1        W update and W^T W partial blocks in one launch (default 1)
+//   "unfused_mid" 0|1    every small kernel and reduction in its own launch (implies no_tail, fused_w 0)
+//   "guided_scalar" 0|1  the per-(covariate, class) scalar form of the H update's guided terms instead of the MFMA products
+//   "tail_stats_per_covariate" 0|1
+//   "sg_variant" 0|1|2   pipeline shape of the float32-MFMA sweep
+//   "x3_variant" -1|0|2  matrix instruction of the x3 sweeps: 0 = 32x32x16, 2 = 16x16x32 general form, -1 = from the data; BEFORE alpine_finalize_X
+//   "x3_narrow" 0|1      512-column workgroup tiles at K <= 64 (default: shards of <= 65 536 cells on the 32x32x16 form); BEFORE alpine_finalize_X
+extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return fail(c, ALPINE_ERR_BAD_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const std::string n(name);
+    const bool before_finalize = n == "x3_variant" || n == "x3_narrow";
+    if (before_finalize && c->x_final) return fail(c, ALPINE_ERR_STATE, "option %s must be set before alpine_finalize_X", name);
+    if (n == "no_tail") c->no_tail = value != 0 || c->unfused_mid;
+    else if (n == "fused_w") c->fused_w = value != 0 && !c->unfused_mid;
+    else if (n == "unfused_mid") { c->unfused_mid = value != 0; if (c->unfused_mid) { c->no_tail = true; c->fused_w = false; } }
+    else if (n == "guided_scalar") c->no_guided_mfma = value != 0;
+    else if (n == "tail_stats_per_covariate") c->tail_stats_per_cov = value != 0;
+    else if (n == "sg_variant") c->sg_variant = value;
+    else if (n == "x3_variant") { if (value != -1 && value != 0 && value != 2) return fail(c, ALPINE_ERR_BAD_ARG, "x3_variant must be -1, 0 or 2"); c->x3_variant = value; }
+    else if (n == "x3_narrow") {
+        if (!c->x3 || c->KT > 2) return 0;                 // only the x3 sweeps at K <= 64 have two tile widths: nothing to switch
+        c->x3_narrow_pref = value != 0; c->x3_narrow_forced = true;
+        c->x3_narrow = c->x3_narrow_pref;
+        apply_sweep_geometry(c, c->x3_narrow ? 512 : 1024);
+    }
+    else return fail(c, ALPINE_ERR_BAD_ARG, "unknown option %s", name);
     c->tail_valid = false;
     return 0;
 }

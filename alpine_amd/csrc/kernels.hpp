@@ -8,13 +8,13 @@
 //     gram_kernel        HH^T  (the K x K factor of ((2W)H)H^T, :599, re-associated)
 //     stream_gemm_kernel XH^T  (:596) over the cells x genes copy of X      <- HOT, MFMA f32
 //   phase 2
-//     w_update_kernel    W <- W * 2XH^T / max(W(2HH^T + orth + l2 I) + l1, eps)  (:596-605, :474-484)
+//     w_update_mfma_kernel    W <- W * 2XH^T / max(W(2HH^T + orth + l2 I) + l1, eps)  (:596-605, :474-484)
 //                        + float64 partials of <XH^T, W_old> for the trace-form loss
 //     loss_finalize      ||X||^2 - 2<XH^T,W> + <W^TW,HH^T>  (== :736), total (:750-752)
 //     b_update_kernel    (:615-628)
 //     gram_kernel        W^T W (the K x K factor of (2W^T)(WH), :654, re-associated)
 //     stream_gemm_kernel W^T X (:653) over the genes x cells copy of X      <- HOT, MFMA f32
-//     h_update_kernel    H <- H * (guided_num + 2W^TX) / max(guided_den + 2W^TW H, eps) (:631-656)
+//     h_update_mfma_kernel    H <- H * (guided_num + 2W^TX) / max(guided_den + 2W^TW H, eps) (:631-656)
 //
 // Layouts (all float32, zero padded): X_gn [Gp][Np], X_ng [Np][Gp] (Gp, Np multiples of 128);
 // W [Gp][KP] gene-major, H [Np][KP] cell-major (KP = K rounded up to 32); Y [sum C_i][Np];
@@ -478,10 +478,12 @@ void reduce_pieces_kernel(const float* __restrict__ pieces, float* __restrict__ 
 }
 
 // Placement report of a sweep launch (alpine_finalize_X's probe, see SweepGeom::dL): workgroup 0 writes the XCC id it runs on.
+// (workgroup 1 reports too: the even/odd bias only makes sense when workgroups 0 and 1 sit on XCCs of different parity -- on a
+// partitioned device whose workgroups all share one XCC it would only unbalance the grid)
 __device__ __forceinline__ void sg_report_xcc(int* __restrict__ xcc_out)
 {
-    if (xcc_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-        *xcc_out = (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u);        // HW_REG_XCC_ID
+    if (xcc_out != nullptr && blockIdx.x < 2 && threadIdx.x == 0)
+        xcc_out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u);        // HW_REG_XCC_ID
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -867,192 +869,10 @@ void phase1_reduce_kernel(Phase1Reduce a, int KP, SweepGeom g)
 }
 
 // ----------------------------------------------------------------------------------------------
-// w_update: rows of W, one wave per 8 gene rows, lane = column k (two columns per lane when KP > 64).
-//   den[g][k] = sum_k' W[g][k'] * M[k'][k] + l1 ,  M = 2 HH^T + orth*(1 - I) + l2*I   (K x K, in LDS)
-//   W[g][k]  *= (2 XH^T[g][k]) / max(den, eps)                                   main.py:596-605
-// Also dotpart[wave] = sum over its rows of XH^T[g][k] * W_old[g][k] in float64 (trace-form loss).
+// rows per wave of the (removed) lane-broadcast update kernels of round 1; still the unit in which the host sizes the float64 partials
+// of <XH^T, W> (alpine_ctx::ndot): the MFMA W update fills one partial per 32 genes, the rest stay zero
 constexpr int UPD_ROWS = 8;
 
-template <int KT>
-__global__ __launch_bounds__(256)
-void w_update_kernel(float* __restrict__ W, const float* __restrict__ XHt, const float* __restrict__ HHt,
-                     double* __restrict__ dotpart, int G, int K, float orth, float l2, float l1, float eps,
-                     int do_update, int k_lo, int k_hi, int block_orth)
-{
-    // MU branch: k_lo = 0, k_hi = K, block_orth = 0.  Block-coordinate branch (main.py:533-545): only the columns
-    // [k_lo, k_hi) of one component group are updated and the orthogonality penalty couples that group's columns only.
-    constexpr int KP = 32 * KT;
-    constexpr int NH = (KP + 63) / 64;
-    extern __shared__ float M[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (do_update) {
-        for (int idx = tid; idx < KP * KP; idx += 256) {
-            const int kp = idx / KP, k = idx % KP;
-            float v = 0.f;
-            if (kp < K && k < K) {
-                const bool coupled = !block_orth || (kp >= k_lo && kp < k_hi);
-                v = 2.f * HHt[idx] + (kp == k ? l2 : (coupled ? orth : 0.f));
-            }
-            M[idx] = v;
-        }
-        __syncthreads();
-    }
-    const int gw = blockIdx.x * 4 + wave;
-    const int g0 = gw * UPD_ROWS;
-    float w[UPD_ROWS][NH], x[UPD_ROWS][NH];
-#pragma unroll
-    for (int i = 0; i < UPD_ROWS; ++i)
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            const int k = lane + 64 * hh;
-            const bool ok = (g0 + i < G) && (k < KP);
-            w[i][hh] = ok ? W[(int64_t)(g0 + i) * KP + k] : 0.f;
-            x[i][hh] = ok ? XHt[(int64_t)(g0 + i) * KP + k] : 0.f;
-        }
-    double dacc = 0.0;
-#pragma unroll
-    for (int i = 0; i < UPD_ROWS; ++i)
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) dacc += (double)x[i][hh] * (double)w[i][hh];
-    dacc = wave_sum_f64(dacc);
-    if (lane == 0) dotpart[gw] = dacc;
-    if (!do_update) return;
-
-    float den[UPD_ROWS][NH];
-#pragma unroll
-    for (int i = 0; i < UPD_ROWS; ++i)
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) den[i][hh] = 0.f;
-#pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-        float mk[NH];
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) mk[hh] = (lane + 64 * hh < KP) ? M[kp * KP + lane + 64 * hh] : 0.f;
-#pragma unroll
-        for (int i = 0; i < UPD_ROWS; ++i) {
-            const float wv = lane_bcast(w[i][kp >> 6], kp & 63);
-#pragma unroll
-            for (int hh = 0; hh < NH; ++hh) den[i][hh] = fmaf(wv, mk[hh], den[i][hh]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < UPD_ROWS; ++i)
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            const int k = lane + 64 * hh;
-            if (g0 + i < G && k >= k_lo && k < k_hi) {
-                const float d = fmaxf(den[i][hh] + l1, eps);
-                W[(int64_t)(g0 + i) * KP + k] = w[i][hh] * ((2.f * x[i][hh]) / d);
-            }
-        }
-}
-
-// ----------------------------------------------------------------------------------------------
-// h_update: rows of H (cells), one wave per 8 cells, lane = component k.
-//   num = guided_num + 2 * sum over the W^TX pieces of n's tile
-//   den = guided_den + sum_k' (2 W^TW)[k'][k] * H[n][k']
-//   H[n][k] *= num / max(den, eps)                                              main.py:631-656
-// guided terms for the columns of covariate i (lanes off_i .. off_i+k_i-1, all within lanes 0..63):
-//   KL : num = sum_c (lam B[c][k]) * (Y[c][n] / max((B H_i)[c][n], eps)),  den = sum_c lam B[c][k]   (:639-644)
-//   Fro: num = sum_c (2 lam B[c][k]) * Y[c][n],  den = sum_c (2 lam B[c][k]) * (B H_i)[c][n]          (:646-647)
-template <int KT>
-__global__ __launch_bounds__(256)
-void h_update_kernel(float* __restrict__ H, const float* __restrict__ pieces, SweepGeom g,
-                     const float* __restrict__ WtW, const float* __restrict__ Y, const float* __restrict__ B,
-                     CovMeta meta, int N, int64_t Np, int K, float eps, int nB)
-{
-    constexpr int KP = 32 * KT;
-    constexpr int NH = (KP + 63) / 64;
-    extern __shared__ float smem[];
-    float* M = smem;               // KP*KP : 2 W^T W
-    float* Bl = smem + KP * KP;    // packed B (nB floats)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int idx = tid; idx < KP * KP; idx += 256) M[idx] = 2.f * WtW[idx];
-    for (int idx = tid; idx < nB; idx += 256) Bl[idx] = B[idx];
-    __syncthreads();
-
-    // which covariate block does column `lane` belong to?
-    int ci = -1, coff = 0, ck = 0, cC = 0, cb = 0, cy = 0;
-    float clam = 0.f;
-    int kmax = 0, Cmax = 0;
-    for (int i = 0; i < meta.n_cov; ++i) {
-        kmax = max(kmax, meta.k[i]);
-        Cmax = max(Cmax, meta.lev[i]);
-        if (lane >= meta.off[i] && lane < meta.off[i] + meta.k[i]) {
-            ci = i; coff = meta.off[i]; ck = meta.k[i]; cC = meta.lev[i]; cb = meta.boff[i]; cy = meta.yoff[i];
-            clam = (meta.loss_type == 0) ? meta.lam[i] : meta.lam2[i];
-        }
-    }
-
-    const int gw = blockIdx.x * 4 + wave;
-    const int64_t n0 = (int64_t)gw * UPD_ROWS;
-    float hv[UPD_ROWS][NH], xv[UPD_ROWS][NH], den[UPD_ROWS][NH];
-    // the wave's 8 cells share one 512-cell tile of the W^TX sweep: sum that tile's pieces in ascending workgroup
-    const int ft = (int)(n0 / g.bf), fl0 = (int)(n0 % g.bf);
-    int w_lo, w_hi;
-    sg_tile_pieces(g, ft, w_lo, w_hi);
-#pragma unroll
-    for (int i = 0; i < UPD_ROWS; ++i)
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            const int k = lane + 64 * hh;
-            const bool ok = (n0 + i < N) && (k < KP);
-            hv[i][hh] = ok ? H[(n0 + i) * KP + k] : 0.f;
-            double a = 0.0;
-            if (ok) for (int w = w_lo; w <= w_hi; ++w) a += (double)pieces[sg_piece_offset(g, w, ft, KP) + (int64_t)(fl0 + i) * KP + k];
-            xv[i][hh] = (float)a;
-            den[i][hh] = 0.f;
-        }
-#pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-        float mk[NH];
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) mk[hh] = (lane + 64 * hh < KP) ? M[kp * KP + lane + 64 * hh] : 0.f;
-#pragma unroll
-        for (int i = 0; i < UPD_ROWS; ++i) {
-            const float b = lane_bcast(hv[i][kp >> 6], kp & 63);
-#pragma unroll
-            for (int hh = 0; hh < NH; ++hh) den[i][hh] = fmaf(b, mk[hh], den[i][hh]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < UPD_ROWS; ++i) {
-        float gnum = 0.f, gden = 0.f;
-        for (int c = 0; c < Cmax; ++c) {
-            float bh = 0.f;
-            for (int kk = 0; kk < kmax; ++kk) {
-                const bool on = (ci >= 0) && (kk < ck) && (c < cC);
-                const float hs = __shfl(hv[i][0], on ? coff + kk : lane, 64);
-                const float bc = on ? Bl[cb + c * ck + kk] : 0.f;
-                bh = fmaf(bc, hs, bh);
-            }
-            if (ci >= 0 && c < cC && n0 + i < N) {
-                const float y = Y[(int64_t)(cy + c) * Np + n0 + i];
-                const float lb = clam * Bl[cb + c * ck + (lane - coff)];
-                if (meta.loss_type == 0) {
-                    gnum = fmaf(lb, y / fmaxf(bh, eps), gnum);
-                    gden += lb;
-                } else {
-                    gnum = fmaf(lb, y, gnum);
-                    gden = fmaf(lb, bh, gden);
-                }
-            }
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            const int k = lane + 64 * hh;
-            if (n0 + i < N && k < K) {
-                const float num = (hh == 0 ? gnum : 0.f) + 2.f * xv[i][hh];
-                const float d = fmaxf((hh == 0 ? gden : 0.f) + den[i][hh], eps);
-                H[(n0 + i) * KP + k] = hv[i][hh] * (num / d);
-            }
-        }
-    }
-}
-
-// Sum of the pieces of tile ft for the k a lane owns in the MFMA C/D layout (k = 32m + 8q + 4h + e), row fl of the tile.
-// Ascending workgroup order, float64 accumulation; all 4*KT float4 loads of one piece are issued together so that a tile
-// with many pieces (small problems on the fixed stream-K grid) costs one memory latency per piece, not one per load.
 template <int KT>
 __device__ __forceinline__ void sg_sum_pieces(const float* __restrict__ pieces, const SweepGeom& g, int ft, int fl, int w_lo, int w_hi,
                                               int h, bool valid, f32x4 (&out)[KT][4])

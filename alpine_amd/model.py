@@ -21,7 +21,7 @@ import torch
 from . import _native
 from .anndata_compat import is_anndata
 from .encoder import FeatureEncoders
-from .sharded import (NativeComm, ShardedLoop, TorchDistComm, all_ranks_ok, attach_native_comm, check_shardable,
+from .sharded import (NativeComm, ShardedLoop, TorchDistComm, all_ranks_ok, attach_native_comm, check_shardable, dmabuf_ipc_problem,
                       ensure_dmabuf_ipc, native_comm_possible, shard_bounds)
 
 Float32Array = np.ndarray
@@ -155,6 +155,7 @@ class ALPINE:
         x_dtype: str = "x3",
         shard_comm: str = "auto",
         keep_resident: bool = False,
+        devices: Optional[List[int]] = None,
     ):
         self.n_components = n_components
         self.n_covariate_components = n_covariate_components
@@ -190,6 +191,22 @@ class ALPINE:
         # costs as much as 50-100 iterations at that size).  The resident copy is used only while adata.X is the same
         # object with the same buffer, shape, strides, dtype AND position-sensitive digest of every byte; any mismatch releases it.
         # release() frees it explicitly.
+        # extension (the reference's fit is ONE blocking call in ONE process, main.py:82-147): devices=[0, 1, ..., P-1] shards
+        # the cell axis over those GPUs of this process -- no launcher, no torch.distributed.  One engine and one host thread per device,
+        # the library's own RCCL communicator over them (ncclCommInitAll), the per-iteration all-reduce enqueued by each engine's C loop.
+        # None (default): the single device named by `device`.  transform / compute_loss run on devices[0].
+        if devices is not None:
+            if not isinstance(devices, (list, tuple)) or len(devices) == 0 or any(not isinstance(d, int) or isinstance(d, bool) or d < 0 for d in devices):
+                raise ValueError("devices must be a non-empty list of non-negative GPU ordinals, e.g. [0, 1, 2, 3]")
+            import os
+            if len(set(devices)) != len(devices) and os.environ.get("ALPINE_AMD_TEST_SHARED_DEVICE") != "1":
+                # (RCCL refuses two ranks on one GPU; the variable is the rehearsal switch of the tests, which preload a stand-in communicator)
+                raise ValueError("devices must not name a GPU twice")
+            if shard_cells:
+                raise ValueError("devices=[...] (one process, several GPUs) and shard_cells (one process per GPU) are alternatives: use one of them")
+            devices = [int(d) for d in devices]
+            self.device = torch.device(f"cuda:{devices[0]}")
+        self.devices = devices
         if not isinstance(keep_resident, bool):
             raise TypeError("keep_resident must be a boolean.")
         self.keep_resident = keep_resident
@@ -257,12 +274,12 @@ class ALPINE:
                 self.max_iter = max_iter
             res = self._run_session(sess, self.max_iter, scale=self.scale_needed)
         except BaseException:
-            sess["eng"].close()
+            self._close_session(sess)
             raise
-        if self.keep_resident and not sess["sharded"] and sess["x_dtype"] in ("f32", "x3") and sess["batch_capacity"] == 0:
+        if self.keep_resident and not sess["sharded"] and not sess.get("multi") and sess["x_dtype"] in ("f32", "x3") and sess["batch_capacity"] == 0:
             self._resident = dict(eng=sess["eng"], X=adata.X, fingerprint=self._x_fingerprint(adata.X), x_dtype=sess["x_dtype"])
         else:
-            sess["eng"].close()
+            self._close_session(sess)
         self.loss_history = res["loss_history"]
         offs = np.cumsum([0] + self.n_all_components)
         X32 = adata.X if adata.X.dtype == np.float32 else adata.X.astype(np.float32)
@@ -276,6 +293,13 @@ class ALPINE:
         self.fit_info = res["info"]
         self.store_embeddings(adata)
         return self
+
+    @staticmethod
+    def _close_session(sess: dict) -> None:
+        for e in sess.get("engs") or [sess["eng"]]:
+            e.close()
+        if sess.get("pool") is not None:
+            sess["pool"].shutdown(wait=False)
 
     def _dist_world(self):
         import torch.distributed as dist
@@ -330,7 +354,7 @@ class ALPINE:
         if self.sampling_method not in ("random", "weighted"):
             raise ValueError(f"Unknown sampling method: {self.sampling_method}. Only 'weighted', and 'random' are supported.")
         if self._uses_batches(n_sample):
-            if self.use_als and self.shard_cells:
+            if self.use_als and (self.shard_cells or (self.devices is not None and len(self.devices) > 1)):
                 raise NotImplementedError("use_als=True with mini-batches is single-device (sharded: full batch only)")
             if self.x_dtype not in ("f32", "x3", "auto"):
                 raise NotImplementedError("mini-batch / weighted sampling needs float32 storage: x_dtype='f32', 'x3' or 'auto'")
@@ -384,8 +408,161 @@ class ALPINE:
         except Exception:       # noqa: BLE001 -- interpreter shutdown
             pass
 
+    # ------------------------------------------------------------------ one process, several GPUs (devices=[...])
+    def _open_session_devices(self, X_cells_genes: np.ndarray, Y: List[np.ndarray]) -> dict:
+        """devices=[d_0 .. d_{P-1}]: engine r on GPU d_r holds the contiguous cell block r (the same cuts as the one-process-per-GPU form),
+        uploads run on P host threads, and ONE ncclCommInitAll attaches the library's communicator to the P engines (rank r = engine r)."""
+        from concurrent.futures import ThreadPoolExecutor
+        N_total, G = X_cells_genes.shape
+        devs = list(self.devices)
+        P = len(devs)
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: alpine_amd needs an MI355X (there is no CPU fallback)")
+        n_vis = torch.cuda.device_count()
+        if max(devs) >= n_vis:
+            raise ValueError(f"devices={devs}: this process sees {n_vis} GPU(s)")
+        check_shardable(N_total, P)
+        bounds = [shard_bounds(N_total, P, r) for r in range(P)]
+        uses_batches = self._uses_batches(N_total)
+        cov_levels = [y.shape[1] for y in Y]
+        x_dtype = self.x_dtype
+        if x_dtype == "auto":
+            x_dtype = "x3" if (uses_batches or self.total_components > self.MAX_FAST_COMPONENTS) else "split"
+        batch_capacity = min(self.batch_size, N_total) if uses_batches else 0
+
+        def make_engine(r: int, dtype: str):
+            c0, c1 = bounds[r]
+            e = _native.NativeShard(n_genes=G, n_cells=c1 - c0, n_components=self.n_components, cov_components=self.n_covariate_components,
+                                    cov_levels=cov_levels, lam=self.lam, orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W,
+                                    eps=self.eps, loss_type=self.loss_type, device_id=devs[r], x_dtype=dtype, batch_capacity=batch_capacity,
+                                    use_als=self.use_als)
+            try:
+                chunk = max(8, ((1 << 28) // (4 * G)) // 8 * 8)
+                for r0 in range(c0, c1, chunk):
+                    r1 = min(c1, r0 + chunk)
+                    e.upload_X_host(np.ascontiguousarray(X_cells_genes[r0:r1], dtype=np.float32), _native.X_CELLS_BY_GENES, r0 - c0)
+                e.finalize_X()
+            except _native.AlpineNativeError as err:
+                e.close()
+                if self.x_dtype == "auto" and dtype == "split" and err.code == -5:
+                    return None                          # this shard's X is not bf16-plane exact: every shard takes x3 (below)
+                raise
+            except Exception:
+                e.close()
+                raise
+            return e
+
+        pool = ThreadPoolExecutor(max_workers=P)
+        engs: List = []
+        try:
+            def build(dtype):
+                futs = [pool.submit(make_engine, r, dtype) for r in range(P)]
+                out, first_err = [], None
+                for f in futs:
+                    try:
+                        out.append(f.result())
+                    except BaseException as e:      # noqa: BLE001 -- collect every engine before raising, so that none leaks
+                        out.append(None)
+                        first_err = first_err or e
+                if first_err is not None:
+                    for e in out:
+                        if e is not None:
+                            e.close()
+                    raise first_err
+                return out
+            engs = build(x_dtype)
+            if any(e is None for e in engs):             # "auto": some shard is not exact in two bf16 planes
+                for e in engs:
+                    if e is not None:
+                        e.close()
+                x_dtype = "x3"
+                engs = build(x_dtype)
+            self.x_dtype_used = x_dtype
+            _native.comm_init_all(engs)
+            counts = [e.comm_count() for e in engs]
+            if any(c != (P, r) for r, c in enumerate(counts)):
+                raise RuntimeError(f"the communicator over devices {devs} reports (ranks, rank) = {counts}")
+            self.shard_comm_used, self.shard_comm_note = "native (one process, ncclCommInitAll)", None
+            for r, e in enumerate(engs):
+                c0, c1 = bounds[r]
+                for i, y in enumerate(Y):
+                    e.upload_Y(i, np.ascontiguousarray(y[c0:c1].T))
+        except BaseException:
+            for e in engs:
+                if e is not None:
+                    e.close()
+            pool.shutdown(wait=False)
+            raise
+        return dict(multi=True, engs=engs, eng=engs[0], pool=pool, bounds=bounds, devices=devs, sharded=False, N_total=N_total, G=G,
+                    cov_levels=cov_levels, Y=Y, x_dtype=x_dtype, batch_capacity=batch_capacity)
+
+    def _run_session_devices(self, sess: dict, n_iter: int, scale: bool) -> dict:
+        """The run of _run_session with one host thread per engine: every composite call (alpine_run, alpine_batch_step, alpine_epoch_loss)
+        is made on all P engines at once and the ranks meet inside the library's all-reduce."""
+        engs, pool, bounds = sess["engs"], sess["pool"], sess["bounds"]
+        N_total, G, cov_levels, Y = sess["N_total"], sess["G"], sess["cov_levels"], sess["Y"]
+        P = len(engs)
+        W0, H0, B0 = draw_initial_factors(self.random_state, self.eps, G, N_total, self.n_all_components, cov_levels)
+        self._rng_post_init = torch.get_rng_state()
+        self._rng_replay = (N_total, n_iter)
+
+        def on_all(fn):
+            """fn(rank, engine) on every engine concurrently (P threads: all of them must be inside a collective together)"""
+            futs = [pool.submit(fn, r, engs[r]) for r in range(P)]
+            errs = []
+            for f in futs:
+                try:
+                    f.result()
+                except BaseException as e:      # noqa: BLE001
+                    errs.append(e)
+            if errs:
+                raise errs[0]
+
+        def init(r, e):
+            e.set_factors(W0, H0, B0, h_col0=bounds[r][0])
+            e.reset_losses()
+        on_all(init)
+        if sess["batch_capacity"] > 0:
+            self._rng_replay = None
+            weights = None
+            if self.sampling_method == "weighted":
+                weights = torch.as_tensor(self._balanced_joint_weights(Y), dtype=torch.double)
+            bs = self.batch_size
+            for _ in range(n_iter):
+                # the reference's index stream, drawn ONCE per epoch on the calling thread (main.py:502-506); every engine takes its cells
+                epoch = (torch.multinomial(weights, N_total, True) if weights is not None else torch.randperm(N_total)).numpy()
+
+                def one_epoch(r, e, epoch=epoch):
+                    c0, c1 = bounds[r]
+                    for b0 in range(0, N_total, bs):
+                        batch = epoch[b0:min(b0 + bs, N_total)]
+                        e.batch_step(batch[(batch >= c0) & (batch < c1)] - c0)
+                    e.epoch_loss()
+                on_all(one_epoch)
+        else:
+            on_all(lambda r, e: e.run(n_iter, with_loss=True))
+        if scale:
+            on_all(lambda r, e: e.scale())
+        parts = [None] * P
+
+        def read(r, e):
+            parts[r] = e.get_factors()
+        on_all(read)
+        W, _, Bs = parts[0]
+        H = np.empty((self.total_components, N_total), dtype=np.float32)
+        for r, (c0, c1) in enumerate(bounds):
+            H[:, c0:c1] = parts[r][1]
+        losses = engs[0].losses()
+        info = engs[0].info()
+        info_d = {f: getattr(info, f) for f, _ in info._fields_}
+        info_d["devices"] = list(sess["devices"])
+        colnames = ["total loss", "reconstruction loss"] + [f"prediction loss({k})" for k in self.covariate_keys]
+        return dict(W=W, H=H, Bs=Bs, loss_history=pd.DataFrame(losses, columns=colnames), info=info_d)
+
     def _open_session(self, X_cells_genes: np.ndarray, Y: List[np.ndarray]) -> dict:
         """Create the engine(s) for this input and upload X and Y once (main.py:445-449); the factors are set per run."""
+        if self.devices is not None:
+            return self._open_session_devices(X_cells_genes, Y)
         N_total, G = X_cells_genes.shape
         dev_index = _parse_device(str(self.device))
         dist, rank, world = self._dist_world()
@@ -393,6 +570,10 @@ class ALPINE:
         local_input = sharded and self.shard_cells == "local"
         if sharded:
             ensure_dmabuf_ipc()                        # before this process's first GPU call, if it has not made one yet
+            # ... and if it HAS (torch.cuda.set_device / init_process_group in every normal torchrun script) without the variable, say so
+            # on every rank now instead of "hipIpcGetMemHandle: invalid argument" from deep inside the first collective
+            problem = dmabuf_ipc_problem(torch.cuda.is_initialized())
+            all_ranks_ok(dist, problem is None, "HSA_ENABLE_IPC_MODE_LEGACY check", RuntimeError(problem) if problem else None)
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: alpine_amd needs an MI355X (there is no CPU fallback)")
         if dev_index < 0:
@@ -494,6 +675,10 @@ class ALPINE:
                             attach_native_comm(eng, dist)
                         except Exception as e:          # noqa: BLE001
                             mode = "torch"
+                            try:
+                                eng.comm_destroy()      # a rank whose own join succeeded must not keep all-reducing natively
+                            except Exception:           # noqa: BLE001 -- nothing was attached
+                                pass
                             self.shard_comm_note = f"native communicator failed ({type(e).__name__}: {e}); fell back to torch.distributed"
                 elif mode == "native":
                     attach_native_comm(eng, dist)
@@ -510,6 +695,8 @@ class ALPINE:
 
     def _run_session(self, sess: dict, n_iter: int, scale: bool) -> dict:
         """Initialise exactly like main.py:436-472, run the MU loop on the resident input, read the factors back."""
+        if sess.get("multi"):
+            return self._run_session_devices(sess, n_iter, scale)
         eng, comm, dist = sess["eng"], sess["comm"], sess["dist"]
         sharded, local_input, dev_index, stream = sess["sharded"], sess["local_input"], sess["dev_index"], sess["stream"]
         N_total, G, c0, c1, cov_levels, Y = sess["N_total"], sess["G"], sess["c0"], sess["c1"], sess["cov_levels"], sess["Y"]

@@ -70,7 +70,33 @@ def ensure_dmabuf_ipc() -> None:
     "hipIpcGetMemHandle: invalid argument" in the legacy mode).  The HIP runtime reads the variable when it starts, so the
     sharded entry points set the default before their first GPU call; a value chosen by the caller is left alone."""
     import os
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        try:
+            import torch
+            late = torch.cuda.is_initialized()
+        except Exception:       # noqa: BLE001
+            late = False
+        if late:
+            os.environ["_ALPINE_AMD_IPC_DEFAULT_SET_LATE"] = "1"     # the runtime is already up: it never saw the value (dmabuf_ipc_problem)
+
+
+def dmabuf_ipc_problem(gpu_runtime_started: bool):
+    """None, or what to tell the user: the HIP runtime reads HSA_ENABLE_IPC_MODE_LEGACY when it starts, so once this process has made a GPU
+    call without it the default set by ensure_dmabuf_ipc comes too late -- and RCCL / torch then fail with "hipIpcGetMemHandle: invalid
+    argument" in the first collective.  (A runtime that has not started yet will see the default: no problem.)"""
+    import os
+    v = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if v == "0":
+        # set by the user, or by ensure_dmabuf_ipc -- which only helps if the runtime had not started when it was set; the caller passes
+        # whether it had, and ensure_dmabuf_ipc records whether the value is its own late default
+        if gpu_runtime_started and os.environ.get("_ALPINE_AMD_IPC_DEFAULT_SET_LATE") == "1":
+            return ("this process initialised the GPU runtime before HSA_ENABLE_IPC_MODE_LEGACY=0 was set: multi-process GPU work on this platform "
+                    "needs dmabuf IPC.  export HSA_ENABLE_IPC_MODE_LEGACY=0 BEFORE the first GPU call (before torch.cuda.set_device / "
+                    "init_process_group), e.g. in the launcher's environment")
+        return None
+    return (f"HSA_ENABLE_IPC_MODE_LEGACY={v!r}: multi-process GPU work on this platform needs dmabuf IPC (RCCL and torch fail with "
+            f"'hipIpcGetMemHandle: invalid argument' otherwise).  export HSA_ENABLE_IPC_MODE_LEGACY=0 before the first GPU call")
 
 
 def attach_native_comm(engine, dist, group=None) -> None:

@@ -394,7 +394,7 @@ def main():
     W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], levels)
     Ys = [np.ascontiguousarray(labels_onehot(N, seed=1 + i)[:, c0:c1]) for i in range(len(kcov))]
 
-    comm_state = {"carrier": None, "note": None}
+    comm_state = {"carrier": None, "native": False, "note": None, "rccl_ranks": None, "rccl_rank": None}
 
     def measure(dtype: str, x_scale: float = None) -> dict:
         """Build the resident state for one storage mode, run `warmup` untimed and `steps` timed iterations."""
@@ -437,6 +437,9 @@ def main():
                         attach_native_comm(eng, dist)
                         comm = NativeComm(eng)
                         comm_state["carrier"] = "native: ncclAllReduce enqueued by libalpine_hip (alpine_run) on the ctx stream"
+                        comm_state["native"] = True
+                        # what the communicator ITSELF reports (ncclCommCount / ncclCommUserRank), not what it was told
+                        comm_state["rccl_ranks"], comm_state["rccl_rank"] = eng.comm_count()
                     except Exception as e:          # noqa: BLE001 -- every rank raised together (all_ranks_ok): fall back together
                         if args.comm == "native":
                             raise
@@ -518,6 +521,7 @@ def main():
             eng.synchronize()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            dt_local = dt
             fence()
             if world > 1:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -532,6 +536,15 @@ def main():
                 ar_ms = ms_c / n_c if n_c else None
             ms_a, n_a = eng.kernel_time(_native.KERNEL_SWEEP_XHT)
             ms_b, n_b = eng.kernel_time(_native.KERNEL_SWEEP_WTX)
+            per_rank = None
+            if world > 1:
+                # every rank's own numbers, so that the one JSON line shows a straggler, a rank on the wrong carrier or a communicator
+                # that saw fewer ranks than the launch (the line's ms_per_step is the MAX over ranks)
+                mine = {"rank": rank, "device": local_rank, "cells": int(n_loc), "ms_per_step": 1e3 * dt_local / args.steps,
+                        "avg_ms_xht": ms_a / max(1, n_a), "avg_ms_wtx": ms_b / max(1, n_b), "allreduce_avg_ms": ar_ms,
+                        "carrier": "native" if comm_state["native"] else "torch", "rccl_ranks": comm_state["rccl_ranks"], "rccl_rank": comm_state["rccl_rank"]}
+                per_rank = [None] * world
+                dist.all_gather_object(per_rank, mine)
             losses = eng.losses()
             eng.set_profiling(False)
             dt_noloss = None
@@ -548,7 +561,7 @@ def main():
             del block
             torch.cuda.empty_cache()
         return dict(dtype=dtype, dt=dt, ms_a=ms_a, n_a=n_a, ms_b=ms_b, n_b=n_b, losses=losses, info=info, t_gen=t_gen, dt_noloss=dt_noloss,
-                    ar_ms=ar_ms, x_scale=x_scale, event_stride=stride, ar_probe=ar_probe)
+                    ar_ms=ar_ms, x_scale=x_scale, event_stride=stride, ar_probe=ar_probe, per_rank=per_rank)
 
     DTYPE_LABEL = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate",
                    "split": "f32 via exact bf16-plane split (bf16 MFMA, f32 accumulate)",
@@ -631,6 +644,17 @@ def main():
             except Exception as e:            # an optional leg must not take the headline down
                 others[key] = {"error": f"{type(e).__name__}: {e}"}
 
+    if world > 1 and rank == 0:
+        # self-verification of the first real multi-rank runs: a native carrier must have been seen by RCCL as `world` ranks with the
+        # launch's rank numbering on EVERY rank, and no rank may be on another carrier than rank 0 -- else the run fails instead of
+        # printing a line that looks like a scaling result
+        pr = main_m["per_rank"] or []
+        bad = [r for r in pr if r["carrier"] != pr[0]["carrier"]
+               or (r["carrier"] == "native" and (r["rccl_ranks"] != world or r["rccl_rank"] != r["rank"]))]
+        if len(pr) != world or bad:
+            print(f"bench.py: the communicator does not match the launch of {world} ranks: {bad or pr}", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
     if rank == 0:
         dt, info, losses = main_m["dt"], main_m["info"], main_m["losses"]
         out = {
@@ -651,6 +675,8 @@ def main():
             "final_loss_row": losses[-1].tolist() if len(losses) else None,
             "allreduce": ({"avg_ms_on_rank0": main_m["ar_ms"], "bytes": int(info.reduce_block_floats) * 4,
                            "carrier": comm_state["carrier"], "fallback_note": comm_state["note"],
+                           "rccl_ranks": comm_state["rccl_ranks"],       # ncclCommCount of the library's communicator (None: torch carrier)
+                           "per_rank": main_m["per_rank"],
                            "note": "avg_ms_on_rank0: hipEvents on the ctx stream around the all-reduce inside the timed loop (transfer + "
                                    "wait for the slowest rank); first_call_ms / standalone_ms: host-timed before the loop, see probe_allreduce",
                            **(main_m["ar_probe"] or {})}

@@ -6,6 +6,11 @@
  *       -Wl,-rpath-link,/opt/rocm/lib
  *   examples/fit_c problem.bin result.bin
  *   examples/fit_c --ranks R problem.bin result.bin     cell axis sharded over R GPUs (devices 0..R-1), one process each
+ *   examples/fit_c --devices D problem.bin result.bin   the same over D GPUs of THIS process: one ctx and one host thread per GPU
+ *
+ * --devices D: no fork, no id exchange -- D ctxs, alpine_comm_init_all (ncclCommInitAll) makes ctx r rank r, then D threads each run the
+ * very call sequence of the one-GPU program on their ctx; the ranks meet inside alpine_run's all-reduce.  (The reference's fit is one
+ * blocking call in one process, alpine/main.py:82-147: this is the form a drop-in binding uses.)
  *
  * --ranks R: the parent forks R workers BEFORE anything touches a GPU.  Worker r takes the cells [N r/R, N (r+1)/R), rank 0
  * draws the RCCL id (alpine_comm_get_unique_id) and publishes it through a file next to the result, every worker joins
@@ -20,6 +25,7 @@
 #ifndef _DEFAULT_SOURCE
 #define _DEFAULT_SOURCE
 #endif
+#include <pthread.h>
 #include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -188,11 +194,121 @@ static int splice(const char* problem, const char* result, int R)
     return 0;
 }
 
+/* ---- --devices D: one process, D ctxs, D host threads ---- */
+typedef struct {
+    alpine_ctx* ctx;
+    int rank, D, C, T, scale;
+    int64_t G, N, c0, c1;
+    const float* X; float* const* Y; float* W; float* H; float* const* B;
+    double* rows; int64_t n_rows;
+    int failed; char err[512];
+} dev_job;
+
+static void* dev_thread(void* arg)
+{
+    dev_job* j = (dev_job*)arg;
+    alpine_ctx* ctx = j->ctx;
+    const int64_t n = j->c1 - j->c0;
+#define STEP(call) do { if (call) { j->failed = 1; snprintf(j->err, sizeof j->err, "%s: %s", #call, alpine_last_error(ctx)); return NULL; } } while (0)
+    STEP(alpine_upload_X_host(ctx, j->X + j->c0 * j->G, ALPINE_X_CELLS_BY_GENES, j->G, 0, n));
+    STEP(alpine_finalize_X(ctx));
+    for (int i = 0; i < j->C; ++i) STEP(alpine_upload_Y(ctx, i, j->Y[i] + j->c0, j->N));
+    STEP(alpine_set_factors(ctx, j->W, j->H + j->c0, j->N, (const float* const*)j->B));
+    STEP(alpine_run(ctx, j->T, 1));                              /* every thread: its kernels + the one all-reduce per iteration */
+    if (j->scale) STEP(alpine_scale(ctx));
+    STEP(alpine_synchronize(ctx));
+    /* W, B and the loss rows are replicated: rank 0 writes them; every rank writes its own columns of H (disjoint) */
+    STEP(alpine_get_factors(ctx, j->rank == 0 ? j->W : NULL, j->H + j->c0, j->N, j->rank == 0 ? j->B : NULL));
+    if (j->rank == 0) STEP(alpine_get_losses(ctx, j->rows, j->T, &j->n_rows));
+#undef STEP
+    return NULL;
+}
+
+static int run_devices(const char* problem, const char* result, int D)
+{
+    FILE* f = fopen(problem, "rb");
+    if (!f) { perror(problem); return 2; }
+    int32_t hdr[9];
+    rd(hdr, sizeof(int32_t), 9, f);
+    if (hdr[0] != 0x414c5031) { fprintf(stderr, "fit_c: bad magic\n"); return 2; }
+    const int64_t G = hdr[1], N = hdr[2];
+    const int Ku = hdr[3], C = hdr[4], T = hdr[7], scale = hdr[8];
+    if (C > MAXC) { fprintf(stderr, "fit_c: too many covariates\n"); return 2; }
+    int32_t k[MAXC], lev[MAXC];
+    int K = Ku;
+    for (int i = 0; i < C; ++i) { int32_t kc[2]; rd(kc, sizeof(int32_t), 2, f); k[i] = kc[0]; lev[i] = kc[1]; K += kc[0]; }
+    double reg[4], lam[MAXC];
+    rd(reg, sizeof(double), 4, f);
+    rd(lam, sizeof(double), (size_t)C, f);
+    float* X = rdf((size_t)(N * G), f);
+    float* Y[MAXC]; float* B[MAXC];
+    for (int i = 0; i < C; ++i) Y[i] = rdf((size_t)(lev[i] * N), f);
+    float* W = rdf((size_t)(G * K), f);
+    float* H = rdf((size_t)(K * N), f);
+    for (int i = 0; i < C; ++i) B[i] = rdf((size_t)(lev[i] * k[i]), f);
+    fclose(f);
+    /* ctx r on device r % FIT_C_DEVICE_COUNT (RCCL wants one device per rank; fewer is for the tests' stand-in communicator) */
+    const char* dc = getenv("FIT_C_DEVICE_COUNT");
+    const int ND = dc && atoi(dc) >= 1 ? atoi(dc) : D;
+    alpine_ctx* ctxs[64] = {0};
+    dev_job jobs[64];
+    memset(jobs, 0, sizeof jobs);
+    for (int r = 0; r < D; ++r) {
+        alpine_config cfg = {0};
+        cfg.struct_size = (int32_t)sizeof(cfg);
+        cfg.device_id = r % ND;
+        cfg.n_genes = G; cfg.n_cells = N * (r + 1) / D - N * r / D;
+        cfg.n_components = Ku; cfg.n_covariates = C;
+        cfg.cov_components = k; cfg.cov_levels = lev; cfg.lam = lam;
+        cfg.orth_W = reg[0]; cfg.alpha_W = reg[1]; cfg.l1_ratio_W = reg[2]; cfg.eps = reg[3];
+        cfg.loss_type = hdr[5];
+        cfg.flags = hdr[6];
+        if (alpine_create(&cfg, &ctxs[r])) die("alpine_create", ctxs[r]);
+    }
+    if (alpine_comm_init_all(ctxs, D)) die("alpine_comm_init_all", ctxs[0]);
+    for (int r = 0; r < D; ++r) {
+        int nr = -1, me = -1;
+        if (alpine_comm_count(ctxs[r], &nr, &me) || nr != D || me != r) { fprintf(stderr, "fit_c: communicator reports %d ranks / rank %d for ctx %d of %d\n", nr, me, r, D); return 1; }
+    }
+    double* rows = (double*)malloc(sizeof(double) * (size_t)(T > 0 ? T : 1) * (size_t)(C + 2));
+    pthread_t th[64];
+    for (int r = 0; r < D; ++r) {
+        dev_job* j = &jobs[r];
+        j->ctx = ctxs[r]; j->rank = r; j->D = D; j->C = C; j->T = T; j->scale = scale;
+        j->G = G; j->N = N; j->c0 = N * r / D; j->c1 = N * (r + 1) / D;
+        j->X = X; j->Y = Y; j->W = W; j->H = H; j->B = B; j->rows = rows;
+        if (pthread_create(&th[r], NULL, dev_thread, j)) { perror("pthread_create"); return 2; }
+    }
+    int bad = 0;
+    for (int r = 0; r < D; ++r) {
+        pthread_join(th[r], NULL);
+        if (jobs[r].failed) { fprintf(stderr, "fit_c: device thread %d failed: %s\n", r, jobs[r].err); bad = 1; }
+    }
+    alpine_info info;
+    if (!bad && alpine_get_info(ctxs[0], &info)) die("alpine_get_info", ctxs[0]);
+    for (int r = 0; r < D; ++r) alpine_destroy(ctxs[r]);
+    if (bad) return 1;
+    FILE* o = fopen(result, "wb");
+    if (!o) { perror(result); return 2; }
+    int32_t n32 = (int32_t)jobs[0].n_rows;
+    fwrite(&n32, sizeof(int32_t), 1, o);
+    fwrite(rows, sizeof(double), (size_t)jobs[0].n_rows * (size_t)(C + 2), o);
+    fwrite(W, sizeof(float), (size_t)(G * K), o);
+    fwrite(H, sizeof(float), (size_t)(K * N), o);
+    for (int i = 0; i < C; ++i) fwrite(B[i], sizeof(float), (size_t)(lev[i] * k[i]), o);
+    fclose(o);
+    printf("fit_c[--devices %d]: G=%lld N=%lld K=%d (padded %d), %lld loss rows, last total loss %.9g\n", D, (long long)G, (long long)N, K, info.k_padded,
+           (long long)jobs[0].n_rows, jobs[0].n_rows ? rows[(jobs[0].n_rows - 1) * (C + 2)] : 0.0);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc == 3) return run_shard(argv[1], argv[2], 0, 0, 0);
+    if (argc == 5 && strcmp(argv[1], "--devices") == 0 && atoi(argv[2]) >= 1 && atoi(argv[2]) <= 64)
+        return run_devices(argv[3], argv[4], atoi(argv[2]));
     if (argc != 5 || strcmp(argv[1], "--ranks") != 0 || atoi(argv[2]) < 1 || atoi(argv[2]) > 64) {
-        fprintf(stderr, "usage: fit_c [--ranks R] problem.bin result.bin\n");
+        fprintf(stderr, "usage: fit_c [--ranks R | --devices D] problem.bin result.bin\n");
         return 2;
     }
     const int R = atoi(argv[2]);

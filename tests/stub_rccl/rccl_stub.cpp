@@ -1,5 +1,6 @@
-// TEST INFRASTRUCTURE, never shipped and never linked into libalpine_hip.so: a shared-memory stand-in for the five RCCL
-// entry points the library calls (ncclGetUniqueId, ncclCommInitRank, ncclAllReduce, ncclCommDestroy, ncclGetErrorString),
+// TEST INFRASTRUCTURE, never shipped and never linked into libalpine_hip.so: a shared-memory stand-in for the RCCL entry
+// points the library calls (ncclGetUniqueId, ncclCommInitRank, ncclCommInitAll, ncclCommCount, ncclCommUserRank, ncclAllReduce,
+// ncclCommDestroy, ncclGetErrorString),
 // preloaded (LD_PRELOAD) into the rank processes of tests/test_gpu_comm_stub.py.
 //
 // Why: RCCL refuses two ranks on one device and the GPU boxes of the test pool have ONE GPU, so the library's native
@@ -26,6 +27,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -48,17 +50,23 @@ sync_fn hip_stream_sync = nullptr;
 
 bool bind_hip()
 {
-    if (hip_memcpy && hip_stream_sync) return true;
-    // global scope first (a plain C host links the runtime directly); a Python process has it in a local scope (pulled in
-    // by an extension module), so ask for the already-loaded object by its soname next; load it only as the last resort
-    void* scopes[3] = {RTLD_DEFAULT, nullptr, nullptr};
-    for (int i = 0; i < 3 && !(hip_memcpy && hip_stream_sync); ++i) {
-        if (i == 1) scopes[i] = dlopen("libamdhip64.so.7", RTLD_NOLOAD | RTLD_LAZY);
-        if (i == 2) scopes[i] = dlopen("libamdhip64.so.7", RTLD_LAZY);
-        if (i > 0 && !scopes[i]) continue;
-        hip_memcpy = (memcpy_fn)dlsym(scopes[i], "hipMemcpy");
-        hip_stream_sync = (sync_fn)dlsym(scopes[i], "hipStreamSynchronize");
-    }
+    // several ranks may live in ONE process (ncclCommInitAll: one host thread per rank): look the runtime up once, into locals, and
+    // publish the pair only when both are found -- a thread must never see a half-bound or a transiently NULL pointer
+    static std::once_flag once;
+    std::call_once(once, [] {
+        memcpy_fn m = nullptr; sync_fn s = nullptr;
+        // global scope first (a plain C host links the runtime directly); a Python process has it in a local scope (pulled in
+        // by an extension module), so ask for the already-loaded object by its soname next; load it only as the last resort
+        void* scopes[3] = {RTLD_DEFAULT, nullptr, nullptr};
+        for (int i = 0; i < 3 && !(m && s); ++i) {
+            if (i == 1) scopes[i] = dlopen("libamdhip64.so.7", RTLD_NOLOAD | RTLD_LAZY);
+            if (i == 2) scopes[i] = dlopen("libamdhip64.so.7", RTLD_LAZY);
+            if (i > 0 && !scopes[i]) continue;
+            m = (memcpy_fn)dlsym(scopes[i], "hipMemcpy");
+            s = (sync_fn)dlsym(scopes[i], "hipStreamSynchronize");
+        }
+        if (m && s) { hip_memcpy = m; hip_stream_sync = s; }
+    });
     return hip_memcpy && hip_stream_sync;
 }
 
@@ -121,6 +129,44 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(WAIT_SECONDS)) { munmap(p, c->bytes); delete c; return ncclSystemError; }
     }
     *out = c;
+    return ncclSuccess;
+}
+
+// one process, ndev ranks (the library's single-process drop-in: one host thread per rank afterwards): the same segment, every
+// rank attached at once
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* /*devlist*/)
+{
+    if (!comms || ndev < 1) return ncclInvalidArgument;
+    ncclUniqueId id;
+    ncclGetUniqueId(&id);
+    const size_t bytes = sizeof(Shared) + sizeof(float) * SLOT_FLOATS * (size_t)ndev;
+    for (int r = 0; r < ndev; ++r) {
+        ncclComm* c = new ncclComm;
+        c->nranks = ndev; c->rank = r; c->bytes = bytes;
+        std::memcpy(c->name, id.internal, sizeof c->name - 1);
+        const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { if (fd >= 0) close(fd); delete c; return ncclSystemError; }
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) { delete c; return ncclSystemError; }
+        c->sh = (Shared*)p;
+        c->sh->attached.fetch_add(1);
+        comms[r] = c;
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count)
+{
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->nranks;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* rank)
+{
+    if (!c || !rank) return ncclInvalidArgument;
+    *rank = c->rank;
     return ncclSuccess;
 }
 

@@ -19,7 +19,7 @@ def build_example():
     build_library()
     cmd = ["gcc", "-O2", "-Wall", "-Werror", "-D_DEFAULT_SOURCE", "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "examples", "fit_c.c"), "-o", EXE,
            "-L" + os.path.join(REPO, "alpine_amd"), "-lalpine_hip", "-Wl,-rpath," + os.path.join(REPO, "alpine_amd"),
-           "-Wl,-rpath-link,/opt/rocm/lib"]
+           "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread"]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     return EXE
 
@@ -111,3 +111,20 @@ def test_c_example_ranks_mode_native_rccl(name, tmp_path):
     assert not os.path.exists(str(res2) + ".id") and not os.path.exists(str(res2) + ".rank0")
     losses, W, H, Bs = read_result(res2, c)
     assert rel_fro(W, c.WT) < 1e-4 and rel_fro(H, c.HT) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kl_2cov_nan", "als_kl"])
+def test_c_example_devices_mode_native_rccl(name, tmp_path):
+    """`fit_c --devices 1`: ONE process, alpine_comm_init_all (ncclCommInitAll over the ctx's device), a host thread drives the ctx and
+    alpine_run enqueues the all-reduce itself; BITWISE the plain single-GPU result (a one-rank sum changes nothing)."""
+    exe = build_example()
+    c = load_case(name)
+    flags = 16 | (4 if c.params.get("use_als") else 0)
+    prob, res1, res2 = tmp_path / "p.bin", tmp_path / "r1.bin", tmp_path / "r2.bin"
+    write_problem(prob, c, flags)
+    r = subprocess.run([exe, str(prob), str(res1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "--devices", "1", str(prob), str(res2)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert open(res1, "rb").read() == open(res2, "rb").read()

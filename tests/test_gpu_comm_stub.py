@@ -177,3 +177,68 @@ def test_als_minibatch_is_refused_on_a_two_rank_communicator(tmp_path):
     for r in range(2):
         msg = open(tmp_path / f"als_mb_rank{r}.txt").read()
         assert msg.startswith("-5:") and "single-shard" in msg, msg
+
+
+@pytest.mark.parametrize("name,D", [("kl_2cov_nan", 2), ("als_kl", 2), ("counts_2cov", 3)])
+def test_c_host_devices_in_one_process(name, D, tmp_path):
+    """examples/fit_c --devices D: ONE process, D ctxs, alpine_comm_init_all, D host threads each running the one-GPU call sequence -- the
+    single-process form of SURVEY.md 8b from plain C (the stand-in carries the bytes: D ctxs share cuda:0 here)."""
+    from test_c_abi_example import build_example, read_result, write_problem
+    exe = build_example()
+    c = load_case(name)
+    flags = 16 | (4 if c.params.get("use_als") else 0)
+    prob, res1, res2 = tmp_path / "p.bin", tmp_path / "r1.bin", tmp_path / "r2.bin"
+    write_problem(prob, c, flags)
+    r = subprocess.run([exe, str(prob), str(res1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with preload_stub():
+        r = subprocess.run([exe, "--devices", str(D), str(prob), str(res2)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, FIT_C_DEVICE_COUNT="1"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    l1, W1, H1, _ = read_result(res1, c)
+    l2, W2, H2, Bs = read_result(res2, c)
+    assert rel_fro(W2, W1) < 2e-5 and rel_fro(H2, H1) < 2e-5
+    assert rel_fro(W2, c.WT) < 1e-4 and rel_fro(H2, c.HT) < 1e-4
+    for b, bt in zip(Bs, c.BT):
+        assert rel_fro(b, bt) < 2e-4
+    assert_loss_rows_close(l2, c.loss_history, n_cells=c.X.shape[0])
+
+
+_DEVICES_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import numpy as np
+from _golden import load_case
+from alpine_amd import ALPINE, MiniAnnData
+c = load_case({case!r})
+fk = dict(c.meta.get("fit_kwargs") or {{}})
+ad = MiniAnnData(c.X.copy(), c.obs.copy())
+m = ALPINE(device="cuda:0", devices={devices!r}, **c.params).fit(ad, covariate_keys=c.keys, max_iter=c.T, **fk)
+np.savez({out!r}, W=np.concatenate(m.matrices["Ws"], axis=1), H=np.concatenate(m.matrices["Hs"], axis=0), losses=m.loss_history.to_numpy(),
+         emb=np.asarray(ad.obsm["ALPINE_embedding"]), comm=str(m.shard_comm_used), devices=np.array(m.fit_info["devices"]),
+         **{{f"B{{i}}": b for i, b in enumerate(m.matrices["Bs"])}})
+"""
+
+
+@pytest.mark.parametrize("case_name,devices", [("kl_2cov_nan", [0, 0]), ("counts_2cov", [0, 0, 0]), ("als_fro_2cov", [0, 0]), ("mb_weighted", [0, 0]),
+                                               ("wide_k150", [0, 0]), ("k105", [0, 0])])
+def test_drop_in_fit_with_devices_in_one_process(case_name, devices, tmp_path):
+    """ALPINE(devices=[...]).fit(adata): one process, one engine and one host thread per listed GPU, the library's communicator over them
+    (alpine_comm_init_all), no launcher and no torch.distributed -- the reference's one blocking call (main.py:82-147).  Rehearsed on one
+    GPU: the engines share cuda:0 (ALPINE_AMD_TEST_SHARED_DEVICE=1) and the stand-in carries the bytes.  Full batch, block-coordinate
+    branch, weighted mini-batches (the epoch's index stream drawn once, every engine takes its cells), K > 64 and K > 128."""
+    import sys
+    c = load_case(case_name)
+    out = str(tmp_path / "r.npz")
+    script = _DEVICES_SCRIPT.format(repo=REPO, case=case_name, devices=devices, out=out)
+    with preload_stub():
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, ALPINE_AMD_TEST_SHARED_DEVICE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(out)
+    assert str(z["comm"]).startswith("native (one process") and list(z["devices"]) == devices
+    assert rel_fro(z["W"], c.WT) < 1e-4 and rel_fro(z["H"], c.HT) < 1e-4
+    for i, bt in enumerate(c.BT):
+        assert rel_fro(z[f"B{i}"], bt) < 2e-4
+    assert_loss_rows_close(z["losses"], c.loss_history, n_cells=c.X.shape[0])
+    assert z["emb"].shape == (c.X.shape[0], c.params["n_components"])

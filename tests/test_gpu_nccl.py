@@ -210,3 +210,38 @@ def test_drop_in_fit_with_native_comm_world_size_one(nccl_group):
     for x, y in zip(a.matrices["Ws"] + a.matrices["Hs"] + a.matrices["Bs"], m.matrices["Ws"] + m.matrices["Hs"] + m.matrices["Bs"]):
         assert np.array_equal(x, y)
     assert np.array_equal(a.loss_history.to_numpy(), m.loss_history.to_numpy())
+
+
+@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "mb_random", "als_kl"])
+def test_drop_in_fit_with_devices_world_size_one_on_real_rccl(case_name):
+    """ALPINE(devices=[0]): the single-process multi-GPU form with ONE device -- ncclCommInitAll on real RCCL, the engine driven from a
+    worker thread, ncclAllReduce enqueued by alpine_run / alpine_batch_step / alpine_epoch_loss.  Against the reference's goldens and
+    BITWISE against the plain single-device fit."""
+    from _golden import assert_loss_rows_close, load_case, rel_fro
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case(case_name)
+    fk = dict(c.meta.get("fit_kwargs") or {})
+    res = []
+    for devices in (None, [0]):
+        ad = MiniAnnData(c.X.copy(), c.obs.copy())
+        m = ALPINE(device="cuda:0", devices=devices, **c.params).fit(ad, covariate_keys=c.keys, max_iter=c.T, **fk)
+        res.append((np.concatenate(m.matrices["Ws"], axis=1), np.concatenate(m.matrices["Hs"], axis=0), m.loss_history.to_numpy()))
+    assert m.shard_comm_used.startswith("native (one process") and m.fit_info["devices"] == [0]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert rel_fro(res[1][0], c.WT) < 1e-4 and rel_fro(res[1][1], c.HT) < 1e-4
+    assert_loss_rows_close(res[1][2], c.loss_history, n_cells=c.X.shape[0])
+
+
+def test_comm_count_reports_what_the_communicator_says(nccl_group):
+    """alpine_comm_count = ncclCommCount / ncclCommUserRank of the attached communicator (what bench.py prints for N > 1 runs)."""
+    from _golden import load_case
+    from alpine_amd import _native
+    from alpine_amd.sharded import attach_native_comm
+    c = load_case("kl_1cov")
+    eng = _engine(c)
+    with pytest.raises(_native.AlpineNativeError, match="no communicator"):
+        eng.comm_count()
+    attach_native_comm(eng, nccl_group)
+    assert eng.comm_count() == (1, 0)
+    eng.comm_destroy()
+    eng.close()

@@ -248,8 +248,7 @@ def test_forced_small_lds_limit_equals_the_default_path(monkeypatch):
                        env={"ALPINE_HIP_LDS_LIMIT": "26000"}, monkeypatch=monkeypatch)
     for mode in ("x3", "f32"):
         assert rel_fro(a[mode][0], b[mode][0]) < 2e-6 and rel_fro(a[mode][1], b[mode][1]) < 2e-6
-        if os.environ.get("ALPINE_HIP_H_UPDATE") != "valu":       # (the knob matrix also runs this file with the VALU form of the H update, which has no tail)
-            assert not (np.array_equal(a[mode][0], b[mode][0]) and np.array_equal(a[mode][1], b[mode][1]))      # the knob did change the launch structure
+        assert not (np.array_equal(a[mode][0], b[mode][0]) and np.array_equal(a[mode][1], b[mode][1]))      # the knob did change the launch structure
 
 
 @pytest.mark.parametrize("seed", [3465])

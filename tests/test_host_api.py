@@ -392,3 +392,39 @@ def test_x_fingerprint_sees_value_edits_and_permutations(monkeypatch):
             X[7, 11] = np.nextafter(X[7, 11], np.float32(np.inf))           # one ulp in one element
             assert ALPINE._x_fingerprint(X) != base, (hide, order, "one ulp")
     monkeypatch.undo()
+
+
+def test_dmabuf_ipc_check_names_the_fix(monkeypatch):
+    """a sharded fit in a process whose GPU runtime started without HSA_ENABLE_IPC_MODE_LEGACY=0 must be told so up front (the
+    late default cannot help), a process that set it -- or whose runtime has not started -- must not be bothered."""
+    import torch
+    from alpine_amd import sharded
+    monkeypatch.delenv("_ALPINE_AMD_IPC_DEFAULT_SET_LATE", raising=False)
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sharded.ensure_dmabuf_ipc()
+    assert sharded.dmabuf_ipc_problem(True) is None and sharded.dmabuf_ipc_problem(False) is None        # the user's own export
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    assert "export HSA_ENABLE_IPC_MODE_LEGACY=0" in sharded.dmabuf_ipc_problem(False)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY")
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
+    sharded.ensure_dmabuf_ipc()                                   # runtime not started: the default arrives in time
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and sharded.dmabuf_ipc_problem(False) is None
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY")
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    sharded.ensure_dmabuf_ipc()                                   # runtime already up: the default is too late, and the check says so
+    msg = sharded.dmabuf_ipc_problem(True)
+    assert msg and "BEFORE the first GPU call" in msg
+    monkeypatch.delenv("_ALPINE_AMD_IPC_DEFAULT_SET_LATE", raising=False)
+
+
+def test_devices_argument_is_validated():
+    from alpine_amd import ALPINE
+    kw = dict(n_components=4, n_covariate_components=[2], lam=[1.0])
+    assert ALPINE(**kw).devices is None
+    m = ALPINE(devices=[1, 0], **kw)
+    assert m.devices == [1, 0] and str(m.device) == "cuda:1"
+    for bad in ([], [0, 0], [-1], ["0"], 3, [True]):
+        with pytest.raises(ValueError):
+            ALPINE(devices=bad, **kw)
+    with pytest.raises(ValueError, match="alternatives"):
+        ALPINE(devices=[0, 1], shard_cells=True, **kw)
