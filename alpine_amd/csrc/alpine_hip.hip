@@ -38,6 +38,8 @@ struct alpine_ctx {
     // wide model (128 < K <= 256, kernels_wide.hpp): KP = 256, KT = 4 = tiles per HALF, factors in the blocked layout [2][rows][128]
     bool wide = false;
     float *wide_den = nullptr, *wide_num = nullptr;     // [2][wide_den_rows][128] product A.M of the updates; [2][Np][128] transform numerator
+    bool wide_one_pass = false;                         // x3 sweeps of a wide model: stream_gemm_x3w2_kernel (X read once per sweep) instead of one x3w launch per component half
+    u32x4* wide_panel3 = nullptr;                       // x3: the panel of the sweep about to run as three exact bf16 planes, k-packed [3][rows / 8][256][8] (stream_gemm_x3w2_kernel)
     int64_t wide_den_rows = 0;
     int64_t Gp = 0, Np = 0;
     std::vector<int> cov_k, cov_lev;
@@ -517,8 +519,13 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         }
         *capA = std::max(*capA, ta * KP); *capB = std::max(*capB, tb * KP);
     };
-    const int bf_default = c->x3 ? (c->KT <= 2 ? 1024 : 512) : c->sweep_waves * SG_WAVE_F;
+    // (wide models on the x3 sweeps: the one-pass kernel stream_gemm_x3w2_kernel, a wave owns 64 columns x all 256 components -- up to
+    // 224 components: with all 16 component tiles its 256 accumulators + X ring + planes no longer fit the register file (68 - 248 B of
+    // scratch per lane in the hot loop: 41 - 70 it/s at K = 256 against 69 on two passes), so K > 224 stays on the two-pass form)
+    c->wide_one_pass = c->wide && c->x3 && !c->x3_ablate && c->K <= 224;
+    const int bf_default = c->x3 ? (c->wide_one_pass ? 256 : (c->KT <= 2 ? 1024 : 512)) : c->sweep_waves * SG_WAVE_F;
     piece_floats(bf_default, &c->piecesA_cap, &c->piecesB_cap);
+    if (c->wide && c->x3 && !c->x3_ablate) piece_floats(c->wide_one_pass ? 512 : 256, &c->piecesA_cap, &c->piecesB_cap);    // (alpine_debug_set_option "wide_one_pass")
     if (c->x3 && c->KT <= 2 && !c->x3_ablate) piece_floats(512, &c->piecesA_cap, &c->piecesB_cap);     // (alpine_debug_set_option "x3_narrow" may ask for it later)
     c->x3_narrow = c->x3_narrow_pref;                 // until alpine_finalize_X knows the data
     apply_sweep_geometry(c, c->x3_narrow ? 512 : bf_default);
@@ -547,6 +554,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
         c->wide_den_rows = std::max(std::max(Gp, Np), round_up(std::max<int64_t>(c->N, cfg->batch_capacity), 128));
         ALLOC(c, c->wide_den, float, c->wide_den_rows * KP);
         ALLOC(c, c->wide_num, float, Np * KP);
+        if (c->x3) ALLOC(c, c->wide_panel3, u32x4, 3 * (c->wide_den_rows / 8) * KP);       // 6 bytes per element of the largest panel (W, H or a view of H)
     }
     ALLOC(c, c->Y, float, (int64_t)std::max(1, c->nYrows) * Np);
     ALLOC(c, c->B[0], float, std::max(1, c->nB));
@@ -633,7 +641,7 @@ extern "C" int alpine_destroy(alpine_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     void* ptrs[] = {c->Xgn, c->Xng, c->W, c->H, c->Y, c->B[0], c->B[1], c->piecesA, c->piecesB, c->own_red ? c->red : nullptr,
-                    c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->rowtab, c->xcc_dev, c->wide_den, c->wide_num, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
+                    c->WtWbuf[0], c->WtWbuf[1], c->Xgn16, c->Xng16, c->Xgn16b, c->Xng16b, c->Wp16, c->Hp16, c->xflags, c->Xb_gn, c->Xb_ng, c->Hb, c->Yb, c->idx_dev, c->gramPart, c->statPart, c->gramPartH, c->statPartH, c->rowtab, c->xcc_dev, c->wide_den, c->wide_num, c->wide_panel3, c->kind, c->dotpart, c->lam_dev, c->loss_dev, c->f64part, c->scale, c->stage};
     for (void* p : ptrs) if (p) (void)dev_free(c, p);
     for (auto& v : c->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -790,6 +798,7 @@ static int sum_f64_partials(alpine_ctx* c, int n, double* out)
 }
 
 static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const float* P, float* pieces, int which, int active16 = 0);
+static int launch_sweeps_wide(alpine_ctx* c, const SweepGeom& g, const float* S, float* P, int64_t rows_pad, float* pieces, int64_t cap, int which);
 
 extern "C" int alpine_finalize_X(alpine_ctx* c)
 {
@@ -856,7 +865,8 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         // results never depend on placement, only this 1 % does.
         c->probe_placement = true;
         HIPCHK(c, hipMemsetAsync(c->xcc_dev, 0xff, sizeof(int) * 2, c->stream));        // -1: "no report" (a one-workgroup grid has no workgroup 1)
-        rc = launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB, 1);
+        rc = c->wide ? launch_sweeps_wide(c, c->geomB, c->Xgn, c->W, c->Gp, c->piecesB, c->piecesB_cap, 1)
+                     : launch_sweep(c, c->geomB, c->Xgn, c->W, c->piecesB, 1);
         c->probe_placement = false;
         if (rc) return rc;
         int hh[2] = {-1, -1};
@@ -993,6 +1003,9 @@ static int launch_gram(alpine_ctx* c, const float* A, int64_t R, int /*blocks_hi
 {
     const int rpw = gram_rows_per_wave(R, c->n_cu);
     const int blocks = (int)((R + 4 * rpw - 1) / (4 * rpw));
+    // (the partial-block buffers are sized at alpine_create from the shard AND the largest mini-batch view; a launch that would write
+    // past them is refused here instead of faulting on the device -- the common shape of the two faults the round-3 fuzz found)
+    if (blocks > c->gramPart_cap) return fail(c, ALPINE_ERR_STATE, "internal: the Gram product of %lld rows needs %d partial blocks, the buffer holds %lld", (long long)R, blocks, (long long)c->gramPart_cap);
     DISPATCH_KT(c->KT, hipLaunchKernelGGL(gram_kernel<KT_>, dim3(blocks), dim3(256), 0, c->stream, A, c->gramPart, (int)R, rpw));
     HIPCHK(c, hipGetLastError());
     const int n = c->KP * c->KP;
@@ -1049,6 +1062,11 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     if (c->bf16) return launch_sweep_bf16(c, which, g);
     const int64_t ldS = c->ablate_stride0 ? 0 : g.F;
     if (c->x3) {
+        // the division must be for THIS kernel's workgroup tile: a wave reads the columns its tile index names
+        const int bf_wg = (c->KT <= 2 && !c->wide && !c->x3_narrow) ? 1024 : 512;
+        if (c->wide_one_pass) return fail(c, ALPINE_ERR_STATE, "internal: a one-pass wide ctx launched a per-half sweep");
+        if (g.bf != bf_wg * g.gw)
+            return fail(c, ALPINE_ERR_STATE, "internal: sweep %d was divided for %d-column workgroup tiles, its kernel works on %d", which, g.bf / std::max(1, g.gw), bf_wg);
         SweepGeom gx = g;
         int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
         if (c->ablate_flush) gx.panel_fixed = 2;
@@ -1142,6 +1160,7 @@ static int phase1(alpine_ctx* c, const CellView& v)
     for (int i = 0; i < c->n_cov; ++i) { max_k = std::max(max_k, c->cov_k[i]); max_c = std::max(max_c, c->cov_lev[i]); }
     const int max_ct = std::min(HS_CT, max_c);
     const size_t hs_bytes = hstats_group_bytes(max_k, max_ct);
+    if (v.statBlocks > c->statPart_cap) return fail(c, ALPINE_ERR_STATE, "internal: %d statistics blocks, the buffer holds %lld", v.statBlocks, (long long)c->statPart_cap);
     if (c->unfused_mid) {            // A/B: every small kernel and every reduction in its own launch
         if (c->n_cov > 0) {
             hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hs_bytes, c->stream, v.H, v.Y, c->B[c->bcur], c->meta,
@@ -1163,6 +1182,9 @@ static int phase1(alpine_ctx* c, const CellView& v)
     const bool from_tail = c->tail_valid && v.H == c->H;
     const int rpw = gram_rows_per_wave(v.Np, c->n_cu);
     const int gblocks = (int)((v.Np + 4 * rpw - 1) / (4 * rpw));
+    if (v.statBlocks > c->statPart_cap || (!from_tail && gblocks > c->gramPart_cap) || (from_tail && v.statBlocks > c->tail_blocks))
+        return fail(c, ALPINE_ERR_STATE, "internal: phase 1 of %d cells needs %d statistics / %d Gram partial blocks, the buffers hold %lld / %lld", v.N, v.statBlocks, gblocks,
+                    (long long)c->statPart_cap, (long long)c->gramPart_cap);
     if (!from_tail) {
         const int stat_blocks2 = c->n_cov > 0 ? (v.statBlocks + 1) / 2 : 0;
         DISPATCH_KT(c->KT, hipLaunchKernelGGL(phase1_open_kernel<KT_>, dim3(gblocks + stat_blocks2), dim3(256), 2 * hs_bytes, c->stream, v.H, c->gramPart,
@@ -1275,6 +1297,8 @@ static int launch_h_update(alpine_ctx* c, const CellView& v, int k_lo, int k_hi,
         tail.merged = (merged_ok && pick->yrows > 0) ? 1 : 0; tail.guided = guided;
         tail.nstat = c->nstat; tail.max_k = max_k; tail.max_ct = max_ct;
         h_bytes_mfma = total_bytes(pick->gm, pick->yrows, pick->tail);
+        if (with_tail && hblocks > c->tail_blocks)
+            return fail(c, ALPINE_ERR_STATE, "internal: the fused tail of %d cells writes %d blocks, its buffers hold %d", v.N, hblocks, c->tail_blocks);
         if (with_tail) { tail.gram_part = c->gramPartH; tail.stat_part = c->statPartH; }
         if (c->loss_type == ALPINE_LOSS_KL) {
             DISPATCH_KT(c->KT, hipLaunchKernelGGL((h_update_mfma_kernel<KT_, 0>), dim3(hblocks), dim3(256), h_bytes_mfma, c->stream, v.H, c->piecesB, v.gB,
@@ -1450,12 +1474,55 @@ static int launch_wide_den(alpine_ctx* c, const float* A, int64_t rows_pad, cons
     return 0;
 }
 
+// The sweep of a wide model over all 256 components: pieces of component half h land in pieces + h * cap / 2 (both [.][128] with the
+// geometry g).  x3: ONE launch of stream_gemm_x3w2_kernel (X read once); float32 MFMA: one launch per half of the blocked panel P.
+static int launch_sweeps_wide(alpine_ctx* c, const SweepGeom& g, const float* S, float* P, int64_t rows_pad, float* pieces, int64_t cap, int which)
+{
+    int rc;
+    const int evt = which == 0 ? ALPINE_KERNEL_SWEEP_XHT : ALPINE_KERNEL_SWEEP_WTX;
+    if (c->wide_one_pass) {
+        const int64_t need = (int64_t)g.nwg * g.maxp * g.bf * WIDE_KH;
+        if (need > cap / 2 || (which == 0 && c->transform_only))
+            return fail(c, ALPINE_ERR_STATE, "internal: sweep %d needs %lld floats of pieces per half, the buffer holds %lld", which, (long long)need, (long long)(cap / 2));
+        if (g.bf != 256 * g.gw) return fail(c, ALPINE_ERR_STATE, "internal: the one-pass wide sweep needs 256-column workgroup tiles");
+        int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
+        const int64_t ldS = g.F;
+        const int m16 = (c->K + 15) / 16;                     // 9..16 tiles with real components; instantiated for the even counts
+        // the panel as three exact bf16 planes, once per sweep (every workgroup tile is only 256 columns wide: splitting it there costs
+        // as much vector work as the X split itself)
+        if (rows_pad > c->wide_den_rows || rows_pad % 8) return fail(c, ALPINE_ERR_STATE, "internal: panel of %lld rows, the plane buffer holds %lld", (long long)rows_pad, (long long)c->wide_den_rows);
+        const int m16i = m16 <= 10 ? 10 : (m16 <= 12 ? 12 : (m16 <= 14 ? 14 : 16));        // the instantiation that runs
+        const int kpa = 16 * m16i;                             // components the sweep stages and multiplies
+        const int64_t plane_stride = (rows_pad / 8) * kpa;
+        hipLaunchKernelGGL(pack_panel3_wide_kernel, dim3((unsigned)std::min<int64_t>((plane_stride + 255) / 256, (int64_t)c->n_cu * 16)), dim3(256), 0, c->stream,
+                           wide_half(P, rows_pad, 0), wide_half(P, rows_pad, 1), (int)rows_pad, kpa, c->wide_panel3, plane_stride);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = prof_begin(c, evt))) return rc;
+        const bool one_plane = c->x_one_plane && c->x3_variant < 0;
+#define X3W2(M_) do { if (one_plane) hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M_, true>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, c->wide_panel3, plane_stride, \
+                                                        pieces, pieces + cap / 2, ldS, g, xcc_out); \
+                      else hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M_, false>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, c->wide_panel3, plane_stride, \
+                                              pieces, pieces + cap / 2, ldS, g, xcc_out); } while (0)
+        if (m16 <= 10) X3W2(10); else if (m16 <= 12) X3W2(12); else if (m16 <= 14) X3W2(14); else X3W2(16);
+#undef X3W2
+        HIPCHK(c, hipGetLastError());
+        return prof_end(c, evt);
+    }
+    for (int h = 0; h < 2; ++h) {
+        if ((rc = prof_begin(c, evt))) return rc;
+        if ((rc = launch_sweep(c, g, S, wide_half(P, rows_pad, h), pieces + h * (cap / 2), which, wide_active16(c, h)))) return rc;
+        if ((rc = prof_end(c, evt))) return rc;
+    }
+    return 0;
+}
+
 static int phase1_wide(alpine_ctx* c, const CellView& v)
 {
     int rc;
     c->prof_now = c->prof && (c->prof_tick++ % c->prof_every) == 0;
     int max_k, max_ct;
     cov_maxima(c, &max_k, &max_ct);
+    if (v.statBlocks > c->statPart_cap) return fail(c, ALPINE_ERR_STATE, "internal: %d statistics blocks, the buffer holds %lld", v.statBlocks, (long long)c->statPart_cap);
     if (c->n_cov > 0) {
         hipLaunchKernelGGL(hstats_kernel, dim3(v.statBlocks), dim3(HS_CELLS), hstats_group_bytes(max_k, max_ct), c->stream, v.H, v.Y, c->B[c->bcur],
                            c->meta, c->statPart, v.N, v.Np, WIDE_KH, (float)c->eps, c->nstat, max_k, max_ct);         // guided components: first half
@@ -1465,13 +1532,9 @@ static int phase1_wide(alpine_ctx* c, const CellView& v)
                        v.statBlocks, c->nstat, c->xnorm2);
     HIPCHK(c, hipGetLastError());
     if ((rc = launch_gram_wide(c, v.H, v.Np, c->red + c->red_hht))) return rc;
-    for (int h = 0; h < 2; ++h) {
-        float* pieces = c->piecesA + h * (c->piecesA_cap / 2);
-        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-        if ((rc = launch_sweep(c, v.gA, v.Xng, wide_half(v.H, v.Np, h), pieces, 0, wide_active16(c, h)))) return rc;
-        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_XHT))) return rc;
-        if ((rc = launch_reduce_pieces(c, pieces, wide_half(c->red, c->Gp, h), (int)c->Gp, v.gA, WIDE_KH))) return rc;
-    }
+    if ((rc = launch_sweeps_wide(c, v.gA, v.Xng, v.H, v.Np, c->piecesA, c->piecesA_cap, 0))) return rc;
+    for (int h = 0; h < 2; ++h)
+        if ((rc = launch_reduce_pieces(c, c->piecesA + h * (c->piecesA_cap / 2), wide_half(c->red, c->Gp, h), (int)c->Gp, v.gA, WIDE_KH))) return rc;
     return 0;
 }
 
@@ -1508,11 +1571,7 @@ static int wide_h_step(alpine_ctx* c, const CellView& v, int k_lo, int k_hi, int
 {
     int rc;
     if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
-    for (int h = 0; h < 2; ++h) {
-        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-        if ((rc = launch_sweep(c, v.gB, v.Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1, wide_active16(c, h)))) return rc;
-        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    }
+    if ((rc = launch_sweeps_wide(c, v.gB, v.Xgn, c->W, c->Gp, c->piecesB, c->piecesB_cap, 1))) return rc;
     if ((rc = launch_wide_den(c, v.H, v.Np, c->WtW, 1, 0, c->K, false))) return rc;
     return wide_h_apply(c, v, nullptr, k_lo, k_hi, only_cov);
 }
@@ -1568,11 +1627,7 @@ static int transform_wide(alpine_ctx* c, int n_iter)
 {
     int rc;
     if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
-    for (int h = 0; h < 2; ++h) {
-        if ((rc = prof_begin(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-        if ((rc = launch_sweep(c, c->geomB, c->Xgn, wide_half(c->W, c->Gp, h), c->piecesB + h * (c->piecesB_cap / 2), 1, wide_active16(c, h)))) return rc;
-        if ((rc = prof_end(c, ALPINE_KERNEL_SWEEP_WTX))) return rc;
-    }
+    if ((rc = launch_sweeps_wide(c, c->geomB, c->Xgn, c->W, c->Gp, c->piecesB, c->piecesB_cap, 1))) return rc;
     const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)c->N + 3) / 4);
     hipLaunchKernelGGL(wide_num_kernel, dim3(blocks), dim3(256), 0, c->stream, c->wide_num, c->piecesB, c->piecesB + c->piecesB_cap / 2, c->geomB, c->N, c->Np);
     HIPCHK(c, hipGetLastError());
@@ -2131,6 +2186,7 @@ extern "C" int alpine_debug_set_xcd_bias(alpine_ctx* c, int per_mille)
 //   "tail_stats_per_covariate" 0|1
 //   "sg_variant" 0|1|2   pipeline shape of the float32-MFMA sweep
 //   "x3_variant" -1|0|2  matrix instruction of the x3 sweeps: 0 = 32x32x16, 2 = 16x16x32 general form, -1 = from the data; BEFORE alpine_finalize_X
+//   "wide_one_pass" 0|1  128 < K <= 256 on the x3 sweeps: one pass over X per sweep (default up to K = 224) or one per component half; BEFORE alpine_finalize_X
 //   "x3_narrow" 0|1      512-column workgroup tiles at K <= 64 (default: shards of <= 65 536 cells on the 32x32x16 form); BEFORE alpine_finalize_X
 extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int value)
 {
@@ -2138,7 +2194,7 @@ extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int valu
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const std::string n(name);
-    const bool before_finalize = n == "x3_variant" || n == "x3_narrow";
+    const bool before_finalize = n == "x3_variant" || n == "x3_narrow" || n == "wide_one_pass";
     if (before_finalize && c->x_final) return fail(c, ALPINE_ERR_STATE, "option %s must be set before alpine_finalize_X", name);
     if (n == "no_tail") c->no_tail = value != 0 || c->unfused_mid;
     else if (n == "fused_w") c->fused_w = value != 0 && !c->unfused_mid;
@@ -2147,6 +2203,11 @@ extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int valu
     else if (n == "tail_stats_per_covariate") c->tail_stats_per_cov = value != 0;
     else if (n == "sg_variant") c->sg_variant = value;
     else if (n == "x3_variant") { if (value != -1 && value != 0 && value != 2) return fail(c, ALPINE_ERR_BAD_ARG, "x3_variant must be -1, 0 or 2"); c->x3_variant = value; }
+    else if (n == "wide_one_pass") {
+        if (!c->wide || !c->x3 || c->x3_ablate) return 0;     // only wide models on the x3 sweeps have the two forms
+        c->wide_one_pass = value != 0;
+        apply_sweep_geometry(c, c->wide_one_pass ? 256 : 512);
+    }
     else if (n == "x3_narrow") {
         if (!c->x3 || c->KT > 2) return 0;                 // only the x3 sweeps at K <= 64 have two tile widths: nothing to switch
         c->x3_narrow_pref = value != 0; c->x3_narrow_forced = true;

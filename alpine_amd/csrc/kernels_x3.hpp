@@ -19,6 +19,7 @@
 // half in flight per wave.  Six bf16 MFMAs per fragment pair cost 6/16 of one float32 MFMA, so the sweep stays near the
 // HBM bound up to K = 128 while the float32-MFMA sweep's time grows with K.
 #pragma once
+#include <type_traits>
 #include "kernels_bf16.hpp"
 
 namespace alpine {
@@ -557,6 +558,246 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
 #pragma unroll
                 for (int m = 0; m < M16; ++m) d[m] = acc[m][4 * cg + tt];
                 sg_flush_tile16<KT>(flush_tr[wave], d, out + (int64_t)(64 * cg + tt) * KP, 4 * KP, lane);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// One pass over X for 128 < K <= 256 ("x3w2", round 4).  The blocked two-half path of kernels_wide.hpp ran every sweep TWICE, once per
+// half of the components (X read four times per iteration: 0.32 of the HBM roof at K = 150).  Here a wave owns 64 columns x ALL 256
+// components -- 16 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 256 registers -- and a workgroup 256 columns, so X is read
+// once per sweep.  What changes against stream_gemm_x3w_kernel:
+//   * a workgroup tile is only 256 columns wide, so the panel is as many bytes per stage as X itself: splitting it into planes in
+//     every workgroup (176 vector instructions per thread and stage, as many as the X split) made a first version no faster than two
+//     passes.  The panel is therefore split ONCE per sweep (pack_panel3_wide_kernel: the blocked factor [2][rows][128] -> three exact
+//     bf16 planes in the k-packed layout [plane][row / 8][256][8], which IS the LDS image: a stage is three contiguous 16 KB chunks)
+//     and a stage is staged by LDS-DMA (global_load_lds_dwordx4), issued at the start of the previous stage: no registers in flight,
+//     no ds_write, no vector arithmetic, a whole stage of MFMAs to land in;
+//   * the A fragments of 16 component tiles x 3 planes do not fit in registers beside the X ring, so the stage is walked component
+//     tile by component tile: 3 ds_read_b128 (one tile ahead), then that tile's products for ALL FOUR column tiles (12 or 24 MFMAs)
+//     -- 48 LDS reads per stage and wave, a quarter of the LDS array's rate;
+//   * for that the four column tiles of the stage are split up front, and the zero-plane decision is taken once per stage and wave
+//     (hi-only only if all four tiles are one-plane); ONEPLANE (census of alpine_finalize_X): no split, no test;
+//   * up front also frees the X registers at the START of a stage: the stage's 8 loads are re-issued for two stages ahead before its
+//     MFMAs run (ring of two stages, 16 KiB per wave in flight for almost two stages of compute);
+//   * the pieces keep the blocked layout the consumers of the two-half path read: components [0, 128) go to pieces0, [128, 256) to
+//     pieces1, both [.][128] with the same geometry -- reduce_pieces_kernel, wide_h_apply_kernel, wide_num_kernel are unchanged.
+// Per accumulator the same products in the same order as x3w (stages ascending; hi x {hi, mid, lo}, mid x {hi, mid}, lo x hi).
+// M16A = 16-component tiles that hold real components (ceil(K / 16), 9..16; the others are never multiplied and flushed as zeros).
+
+// the blocked factor [2][rows_pad][128] -> three exact bf16 planes of its first kpa components (kpa = 16 x the component tiles the
+// sweep multiplies: the padding columns of a K = 150 model are a third of the panel's bytes), k-packed: dst[q][rb][comp][8] (rb = row / 8),
+// plane stride in u32x4
+__global__ __launch_bounds__(256)
+void pack_panel3_wide_kernel(const float* __restrict__ P0, const float* __restrict__ P1, int rows, int kpa, u32x4* __restrict__ dst, int64_t plane_stride)
+{
+    const int64_t n = (int64_t)(rows / 8) * kpa;               // granules: (rb, comp)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t rb = i / kpa;
+        const int comp = (int)(i - rb * kpa);
+        const float* src = (comp < 128 ? P0 : P1) + rb * 8 * 128 + (comp & 127);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[e * 128];
+        u32x4 o[3];
+        x3_split8_scalar(v, o);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dst[q * plane_stride + i] = o[q];
+    }
+}
+
+template <int M16A, bool ONEPLANE = false>
+__global__ __launch_bounds__(256, 1)
+void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restrict__ Pk, int64_t plane_stride,
+                             float* __restrict__ pieces0, float* __restrict__ pieces1, int64_t ldS, SweepGeom g, int* __restrict__ xcc_out)
+{
+    sg_report_xcc(xcc_out);
+    static_assert(M16A >= 9 && M16A <= 16, "active 16-component tiles of a wide model");
+    constexpr int KH = 128;
+    constexpr int KP = 16 * M16A;                                     // panel components staged and multiplied (the pieces stay 2 x 128 wide)
+    constexpr int WAVE_F = 64, BLOCK_F = 4 * WAVE_F;
+    constexpr int ROWS = 32;                                          // rows per k-step = per panel stage
+    static_assert(SG_ROW_ALIGN % ROWS == 0, "stream-K spans are whole stages");
+    constexpr int STAGE_BF16 = ROWS * KP;                             // bf16 elements of one plane of a stage (16 KB)
+    constexpr int STAGE_V4 = STAGE_BF16 / 8;                          // ... in 16-byte granules (64 per component tile = 1 KiB)
+    constexpr int PIECES = 3 * M16A;                                  // 1-KiB pieces of a stage image [plane][M16A KiB]
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * STAGE_BF16];          // 6 KB per component tile and buffer: 96 KB at M16A = 16
+    __shared__ __attribute__((aligned(16))) float flush_tr[4][16 * (KH + 4)];              // 33 KB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kg = lane >> 4;
+    SgWalk walk;
+    int team, member;
+    sg_team_of_block(g, blockIdx.x, team, member);
+    sg_walk_init(walk, g, team);
+
+    f32x4 x[2][8];
+
+    int ft, r_begin, r_end;
+    int64_t slot;
+    while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
+        const int nst = (r_end - r_begin) / ROWS;
+        const int wt = ft * g.gw + member;                 // this workgroup's BLOCK_F-wide tile (ft = the team's tile)
+        if ((int64_t)wt * BLOCK_F >= g.F) continue;        // a member past the last column of a partly filled team tile (block-uniform)
+        const int f0 = (wt * 4 + wave) * WAVE_F;
+        const bool active = f0 < g.F;
+
+        // Panel stage t -> LDS buffer b by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = one contiguous KiB of the LDS image per
+        // wave-instruction, no vector registers, no ds_write): the stage image is 3 x M16A pieces of 1 KiB ([plane][M16A KiB]); wave w copies the
+        // pieces 4 i + w.  hipcc does not see these loads (inline assembly: M0 = the LDS address, saved and restored around the
+        // instruction), so THIS code waits for them -- dma_wait before the barrier that publishes the buffer; they retire in order with the X
+        // loads, whose waits the compiler still counts itself (a hidden older load only makes such a wait cover more, never less).
+        const u32x4* pbase = Pk + (int64_t)(r_begin / 8) * KP + lane;
+        auto dma_stage = [&](int t, int b) {
+            const unsigned lbase = (unsigned)(size_t)(&lds[b][0]);
+#pragma unroll
+            for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+                const int piece = 4 * i + wave;                     // wave-uniform
+                if (piece >= PIECES) break;
+                const int q = piece / M16A, kk = piece % M16A;      // plane, KiB within the plane's M16A KiB
+                const u32x4* src = pbase + q * plane_stride + (int64_t)t * STAGE_V4 + kk * 64;
+                const unsigned dst = lbase + (unsigned)(q * 2 * STAGE_BF16 + kk * 1024);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        };
+        // all but the `younger` youngest vector-memory operations of this wave have completed (the panel DMAs are older than an X reload issued after them)
+        auto dma_wait = [&](bool x_reload_after) {
+            if (x_reload_after) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+
+        __syncthreads();
+        dma_stage(0, 0);
+
+        if (!active) {
+            // a wave whose 64 columns lie past F: the panel staging and EVERY barrier of the loop below, nothing else (kept apart from
+            // the computing path: accumulators that are updated under a condition make the compiler shuffle them between register classes)
+            dma_wait(false);
+            __syncthreads();
+            for (int t = 0; t < nst; ++t) {
+                if (t + 1 < nst) dma_stage(t + 1, (t + 1) & 1);
+                dma_wait(false);
+                __syncthreads();
+            }
+            continue;
+        }
+
+        f32x4 acc[M16A][4];                                 // (only the tiles with real components; the others are flushed as zeros)
+#pragma unroll
+        for (int m = 0; m < M16A; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // this lane's float4 of row r_begin + 8 kg (+ e), columns f0 + 4 c16 .. + 3 (element t -> column tile t, column c16)
+        const float* xbase = S + (int64_t)(r_begin + 8 * kg) * ldS + f0 + 4 * c16;
+        const int64_t x_stage = (int64_t)ROWS * ldS;
+        const int lds_lane = (kg * KP + c16) * 8;
+
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)         // (a one-stage span re-reads stage 0 into the second slot: valid memory, never used)
+                x[p][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (int64_t)(p < nst ? p : 0) * x_stage + (int64_t)e * ldS));
+        __builtin_amdgcn_sched_barrier(0);
+        dma_wait(false);                 // (stage 0's panel; also drains the X prologue once per span)
+        __syncthreads();
+
+        // stage t on ring slot P_ (= t & 1 = its panel buffer): split the four column tiles, start the NEXT stage's panel on its way into
+        // the other buffer, re-issue the slot for stage t + 2, then component tile by component tile
+        auto stage = [&](auto slot_c, int t) {
+            constexpr int P_ = decltype(slot_c)::value;
+            const unsigned short* __restrict__ lrow = &lds[P_][lds_lane];
+            const bool more = t + 1 < nst;
+            u32x4 b[4][3];
+            unsigned rest = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x[P_][e][j];
+                if constexpr (ONEPLANE) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[j][0][q] = x3_cvt2(v[2 * q], v[2 * q + 1]);       // exact: every value is one bf16 plane
+                    b[j][1] = b[j][2] = u32x4{0u, 0u, 0u, 0u};
+                } else {
+                    x3_split8_scalar(v, b[j]);
+                    rest |= b[j][1][0] | b[j][1][1] | b[j][1][2] | b[j][1][3];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) dma_stage(t + 1, P_ ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nst) {
+                const float* src = xbase + (int64_t)(t + 2) * x_stage;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[P_][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (int64_t)e * ldS));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto lda = [&](int m, u32x4 (&a)[3]) {
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) a[pp] = *reinterpret_cast<const u32x4*>(lrow + pp * STAGE_BF16 + (16 * m) * 8);
+            };
+            u32x4 a[2][3];
+            lda(0, a[0]);
+            // (an if-THEN per component tile, not two copies of the loop under an if / else: with the accumulators updated on two
+            // different paths the register allocator no longer keeps each in ONE accumulator register across the join and shuttles them
+            // through vector registers -- 1 040 v_accvgpr moves and 356 B of scratch per lane in that form, none in this one)
+            const bool full = !ONEPLANE && __builtin_amdgcn_ballot_w64((rest & 0x7fff7fffu) != 0u) != 0ull;
+#pragma unroll
+            for (int m = 0; m < M16A; ++m) {
+                asm volatile("" ::: "memory");              // (no motion of the fragment reads across component tiles before scheduling either)
+                if (m + 1 < M16A) lda(m + 1, a[(m + 1) & 1]);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m & 1][pp]), __builtin_bit_cast(bf16x8, b[j][0]), acc[m][j], 0, 0, 0);
+                if (full) {
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m & 1][pp]), __builtin_bit_cast(bf16x8, b[j][1]), acc[m][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m & 1][0]), __builtin_bit_cast(bf16x8, b[j][2]), acc[m][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dma_wait(t + 2 < nst);                          // the next stage's panel has landed (this wave's share) before the barrier publishes it
+        };
+        using Slot0 = std::integral_constant<int, 0>;
+        using Slot1 = std::integral_constant<int, 1>;
+
+        int t = 0;
+        for (; t + 1 < nst; t += 2) {
+            stage(Slot0{}, t);
+            __syncthreads();
+            stage(Slot1{}, t + 1);
+            __syncthreads();
+        }
+        if (t < nst) { stage(Slot0{}, t); __syncthreads(); }
+
+        // D: component = 16 m + 4 kg + e, column = c16 -> f_local = WAVE_F * wave + 4 c16 + tile; components [0, 128) -> pieces0, the rest -> pieces1
+        const int64_t off = (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KH;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float* out = (hh == 0 ? pieces0 : pieces1) + off;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 d[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) d[m] = (8 * hh + m < M16A) ? acc[(8 * hh + m < M16A) ? 8 * hh + m : 0][tt] : f32x4{0.f, 0.f, 0.f, 0.f};
+                sg_flush_tile16<4>(flush_tr[wave], d, out + (int64_t)tt * KH, 4 * KH, lane);
             }
         }
     }

@@ -572,7 +572,8 @@ def main():
         mf = dtype == "f32"
         launches = m["n_a"] + m["n_b"]
         avg_ms = (m["ms_a"] + m["ms_b"]) / max(1, launches)
-        passes = 2 if K > 128 else 1                               # 128 < K <= 256: each sweep is two launches, one per component half
+        one_pass = K > 128 and dtype == "x3" and K <= 224           # the library's rule (alpine_create): stream_gemm_x3w2_kernel up to 224 components
+        passes = 2 if (K > 128 and not one_pass) else 1            # else each sweep of a wide model is two launches, one per component half
         flops_per_launch = 2.0 * G * n_loc * K / passes           # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
         bytes_per_launch = (4.0 if dtype in ("f32", "x3") else 2.0) * G * n_loc   # X read once per sweep (counts: ONE bf16 plane in split mode)
         ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -581,6 +582,8 @@ def main():
         # models with a padding tile -- alpine_finalize_X decides from a census of X and reports it in alpine_info.x3_wide
         if mf:
             kname, kdesc = "stream_gemm_kernel", "MFMA f32 32x32x2"
+        elif one_pass:
+            kname, kdesc = "stream_gemm_x3w2_kernel", "one pass over X for 128 < K <= 256: float32 X split into exact bf16 planes in registers, MFMA bf16 16x16x32"
         elif dtype == "x3" and info.x3_wide:
             kname, kdesc = "stream_gemm_x3w_kernel", "float32 X split into exact bf16 planes in registers, MFMA bf16 16x16x32"
         elif dtype == "x3":

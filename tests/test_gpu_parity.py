@@ -1020,3 +1020,41 @@ def test_one_plane_form_of_the_wide_sweeps_is_bitwise_the_general_form(name, K):
     assert rel_fro(d.get_factors()[0], f.get_factors()[0]) < 2e-5
     d.close()
     f.close()
+
+
+@pytest.mark.parametrize("name", ["wide_k150", "wide_k200_fro", "als_wide_k160_fro", "mb_wide_k150"])
+def test_wide_one_pass_and_two_pass_sweeps_agree_with_the_reference(name):
+    """128 < K <= 256 on the x3 sweeps: stream_gemm_x3w2_kernel reads X ONCE per sweep (a wave owns 64 columns x all 256 components, the
+    panel pre-split once per sweep and staged by LDS-DMA; the library's choice up to K = 224), the round-3 form runs one x3w launch per
+    component half.  Same pieces layout, same consumers: both must meet the reference tolerances and agree with each other."""
+    from alpine_amd import ALPINE, MiniAnnData
+    c = load_case(name)
+    res = {}
+    for one_pass in (1, 0):
+        if c.fit_kwargs:                                  # mini-batch cases: through the drop-in class (the option is per engine: patch it in)
+            nat = _native()
+            real = nat.NativeShard.upload_X_host
+
+            def first_upload(self, X, *a, _real=real, _v=one_pass, **kw):
+                if not getattr(self, "_opt_done", False):
+                    self.debug_set_option("wide_one_pass", _v)
+                    self._opt_done = True
+                return _real(self, X, *a, **kw)
+            nat.NativeShard.upload_X_host = first_upload
+            try:
+                ad = MiniAnnData(c.X.copy(), c.obs.copy())
+                m = ALPINE(device="cuda", scale_needed=False, **{k: v for k, v in c.params.items() if k != "scale_needed"}).fit(
+                    ad, covariate_keys=c.keys, max_iter=c.T, **c.fit_kwargs)
+            finally:
+                nat.NativeShard.upload_X_host = real
+            W, H = np.concatenate(m.matrices["Ws"], axis=1), np.concatenate(m.matrices["Hs"], axis=0)
+            losses = m.loss_history.to_numpy()
+        else:
+            eng = make_engine(c, x_dtype="x3", options={"wide_one_pass": one_pass})
+            eng.run(c.T, with_loss=True)
+            (W, H, _), losses = eng.get_factors(), eng.losses()
+            eng.close()
+        res[one_pass] = (W, H, losses)
+        assert rel_fro(W, c.WT_unscaled) < 1e-4 and rel_fro(H, c.HT_unscaled) < 1e-4, (name, one_pass)
+        assert_loss_rows_close(losses, c.loss_history, n_cells=c.X.shape[0])
+    assert rel_fro(res[1][0], res[0][0]) < 2e-5 and rel_fro(res[1][1], res[0][1]) < 2e-5
