@@ -125,6 +125,19 @@ def draw_initial_factors(random_state: int, eps: float, n_features: int, n_sampl
     return torch.cat(Ws, dim=1).numpy(), torch.cat(Hs, dim=0).numpy(), [b.numpy() for b in Bs]
 
 
+def _maybe_two_bf16_planes(X: np.ndarray, max_rows: int = 64) -> bool:
+    """Cheap host-side screen for x_dtype="auto": could X be stored exactly as two bf16 planes (16 significant bits: integer counts
+    < 65 536 and the like)?  Looks at up to `max_rows` rows spread over the matrix: False as soon as one float32 value has any of its low
+    8 significand bits set -- then the exact-split storage would be refused by the library anyway (alpine_finalize_X) and trying it
+    first would cost a whole extra upload.  True only means "worth trying": the library still checks every element."""
+    if X.size == 0:
+        return True
+    n = X.shape[0]
+    rows = np.unique(np.linspace(0, n - 1, num=min(n, max_rows)).astype(np.int64))
+    sample = np.ascontiguousarray(X[rows], dtype=np.float32)
+    return not bool((sample.view(np.uint32) & np.uint32(0xFF)).any())
+
+
 def _parse_device(device: str) -> int:
     d = torch.device(device)
     if d.type == "cpu":
@@ -152,7 +165,7 @@ class ALPINE:
         eps: float = 1e-6,
         random_state: int = 42,
         shard_cells: Union[bool, str] = False,
-        x_dtype: str = "x3",
+        x_dtype: str = "auto",
         shard_comm: str = "auto",
         keep_resident: bool = False,
         devices: Optional[List[int]] = None,
@@ -212,13 +225,15 @@ class ALPINE:
         self.keep_resident = keep_resident
         self._resident = None
         # extension: storage / matrix-pipe mode of the two sweeps (the reference has float32 only).
-        #   "x3" (default)  X float32 in HBM; every product is formed from the exact bf16 planes of both factors on the
+        #   "auto" (default) "split" when X allows it (integer counts: bit-identical to "x3" at half the memory and 1.8 x the
+        #                   iterations per second), else "x3".  A sample of X decides up front whether "split" is worth trying
+        #                   (_maybe_two_bf16_planes), so data with full significands costs no second upload.
+        #   "x3"            X float32 in HBM; every product is formed from the exact bf16 planes of both factors on the
         #                   bf16 matrix pipe (six plane products, float32 accumulate): float32-grade results for ANY X at
         #                   HBM-bound instead of float32-MFMA-bound speed.
         #   "f32"           the float32 MFMA (v_mfma_f32_32x32x2_f32) on the same float32 storage.
         #   "split"         X stored as 1-2 bf16 planes that sum EXACTLY to the input (integer counts): float32-grade
         #                   results at half the memory and traffic; raises if X has more than 16 significant bits.
-        #   "auto"          "split" when X allows it, else "x3".
         #   "bf16"          X and the operand copies of W/H rounded to bf16 (fp32 accumulation, fp32 masters): NOT
         #                   float32-grade, tolerance in DESIGN.md.
         if x_dtype not in ("f32", "x3", "bf16", "split", "auto"):
@@ -427,7 +442,8 @@ class ALPINE:
         cov_levels = [y.shape[1] for y in Y]
         x_dtype = self.x_dtype
         if x_dtype == "auto":
-            x_dtype = "x3" if (uses_batches or self.total_components > self.MAX_FAST_COMPONENTS) else "split"
+            no_split = uses_batches or self.total_components > self.MAX_FAST_COMPONENTS or not _maybe_two_bf16_planes(X_cells_genes)
+            x_dtype = "x3" if no_split else "split"
         batch_capacity = min(self.batch_size, N_total) if uses_batches else 0
 
         def make_engine(r: int, dtype: str):
@@ -599,7 +615,15 @@ class ALPINE:
 
         x_dtype = self.x_dtype
         if x_dtype == "auto":
-            x_dtype = "x3" if (uses_batches or self.total_components > self.MAX_FAST_COMPONENTS) else "split"
+            # the exact-split storage needs full batches on K <= 128, does not serve a resident engine (compute_loss evaluates on the
+            # float32 copy), and is only tried when a sample of this rank's rows says X may qualify
+            no_split = (uses_batches or self.total_components > self.MAX_FAST_COMPONENTS or self.keep_resident
+                        or not _maybe_two_bf16_planes(X_cells_genes[row0:row0 + n_loc]))
+            if sharded:                                # one choice for all ranks (a rank-local one would desynchronise the collectives below)
+                votes = [None] * world
+                dist.all_gather_object(votes, bool(no_split))
+                no_split = any(votes)
+            x_dtype = "x3" if no_split else "split"
         kw = dict(n_genes=G, n_cells=n_loc, n_components=self.n_components,
                   cov_components=self.n_covariate_components, cov_levels=cov_levels, lam=self.lam,
                   orth_W=self.orth_W, alpha_W=self.alpha_W, l1_ratio_W=self.l1_ratio_W, eps=self.eps,
@@ -820,7 +844,8 @@ class ALPINE:
             resident.transform(n_iter)
             _, H, _ = resident.get_factors()
         else:
-            x_dtype = ("x3" if self.total_components > self.MAX_FAST_COMPONENTS else "split") if self.x_dtype == "auto" else self.x_dtype
+            x_dtype = (("x3" if (self.total_components > self.MAX_FAST_COMPONENTS or not _maybe_two_bf16_planes(X)) else "split")
+                       if self.x_dtype == "auto" else self.x_dtype)
             try:
                 eng = make_engine(x_dtype)
             except _native.AlpineNativeError as err:

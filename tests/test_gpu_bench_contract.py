@@ -61,6 +61,11 @@ def test_bench_gpus_2_launches_its_own_workers():
     assert d["config"]["parallelism"] == "cells/2" and d["config"]["cells_per_gpu"] in (2496, 2504)
     ar = d["allreduce"]
     assert ar is not None and ar["avg_ms_on_rank0"] > 0 and ar["bytes"] > 0 and ar["carrier"]
+    assert len(ar["per_rank"]) == 2 and all(r["ms_per_step"] > 0 for r in ar["per_rank"])
+    if ar["carrier"].startswith("native"):
+        assert ar["rccl_ranks"] == 2
+    else:
+        assert ar["rccl_ranks"] is None and all(r["carrier"] == "torch" for r in ar["per_rank"])
 
 
 def test_bench_under_the_drivers_launcher_command():

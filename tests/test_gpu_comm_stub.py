@@ -136,6 +136,12 @@ def test_bench_two_ranks_native_carrier():
     ar = d["allreduce"]
     assert ar["carrier"].startswith("native") and ar["fallback_note"] is None
     assert ar["avg_ms_on_rank0"] > 0 and ar["bytes"] > 0
+    # the line verifies itself: what the communicator reports, and every rank's own numbers
+    assert ar["rccl_ranks"] == 2
+    pr = ar["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["carrier"] == "native" and r["rccl_ranks"] == 2 and r["rccl_rank"] == r["rank"] for r in pr)
+    assert all(r["ms_per_step"] > 0 and r["avg_ms_xht"] > 0 and r["avg_ms_wtx"] > 0 and r["cells"] > 0 for r in pr)
+    assert abs(max(r["ms_per_step"] for r in pr) - d["ms_per_step"]) <= 1e-6 * d["ms_per_step"]
 
 
 def _als_minibatch_worker(rank, world, port, out_dir):

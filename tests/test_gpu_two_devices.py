@@ -40,3 +40,32 @@ def test_two_ranks_on_two_gpus(case_name, local, comm, tmp_path):
         single = ALPINE(device="cuda:0", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
         assert rel_fro(r[0]["W"], np.concatenate(single.matrices["Ws"], axis=1)) < 2e-5
         assert rel_fro(H, np.concatenate(single.matrices["Hs"], axis=0)) < 2e-5
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "counts_2cov", "als_kl", "mb_weighted", "k105"])
+def test_devices_in_one_process_on_two_gpus(case_name, tmp_path):
+    """ALPINE(devices=[0, 1]).fit(adata) in a fresh process (no launcher, no torch.distributed): ncclCommInitAll over the two GPUs, one host
+    thread per engine, the all-reduce over xGMI enqueued by the library's C loop.  Against the goldens and the single-device fit."""
+    import os
+    import subprocess
+    import sys
+    from _golden import assert_loss_rows_close, load_case, rel_fro
+    from alpine_amd import ALPINE, MiniAnnData
+    from test_gpu_comm_stub import _DEVICES_SCRIPT, REPO
+    c = load_case(case_name)
+    out = str(tmp_path / "r.npz")
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    r = subprocess.run([sys.executable, "-c", _DEVICES_SCRIPT.format(repo=REPO, case=case_name, devices=[0, 1], out=out)], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(out)
+    assert str(z["comm"]).startswith("native (one process") and list(z["devices"]) == [0, 1]
+    assert rel_fro(z["W"], c.WT) < 1e-4 and rel_fro(z["H"], c.HT) < 1e-4
+    for i, bt in enumerate(c.BT):
+        assert rel_fro(z[f"B{i}"], bt) < 2e-4
+    assert_loss_rows_close(z["losses"], c.loss_history, n_cells=c.X.shape[0])
+    if not c.fit_kwargs and not c.params.get("use_als"):
+        single = ALPINE(device="cuda:0", **c.params).fit(MiniAnnData(c.X.copy(), c.obs.copy()), covariate_keys=c.keys, max_iter=c.T)
+        assert rel_fro(z["W"], np.concatenate(single.matrices["Ws"], axis=1)) < 2e-5
+        assert rel_fro(z["H"], np.concatenate(single.matrices["Hs"], axis=0)) < 2e-5

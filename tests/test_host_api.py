@@ -428,3 +428,21 @@ def test_devices_argument_is_validated():
             ALPINE(devices=bad, **kw)
     with pytest.raises(ValueError, match="alternatives"):
         ALPINE(devices=[0, 1], shard_cells=True, **kw)
+
+
+def test_auto_storage_screen():
+    """x_dtype="auto" (the default): a sample of X decides whether the exact two-plane storage is worth trying -- integer counts yes,
+    values with more than 16 significant bits no (the library would refuse them after a whole upload), conservative for odd values."""
+    from alpine_amd import ALPINE
+    from alpine_amd.model import _maybe_two_bf16_planes
+    rng = np.random.default_rng(0)
+    assert ALPINE(n_components=3, n_covariate_components=[1], lam=[1.0]).x_dtype == "auto"
+    counts = rng.poisson(3.0, size=(500, 40)).astype(np.float32)
+    assert _maybe_two_bf16_planes(counts) and _maybe_two_bf16_planes(counts * 200.0) and _maybe_two_bf16_planes(counts.astype(np.float64))
+    assert not _maybe_two_bf16_planes(rng.gamma(0.3, 3.0, size=(500, 40)).astype(np.float32))
+    assert not _maybe_two_bf16_planes(np.log1p(counts))
+    big = counts.copy(); big[250, 7] = 65537.0                     # 17 significant bits in a sampled row
+    rows = np.unique(np.linspace(0, 499, num=64).astype(np.int64))
+    big[rows[10], 7] = 65537.0
+    assert not _maybe_two_bf16_planes(big)
+    assert _maybe_two_bf16_planes(np.zeros((0, 5), dtype=np.float32))
