@@ -1,4 +1,7 @@
-"""A/B of library knobs in ONE process, interleaved rounds (cdna_hip_programming.md rule 24): one engine per variant
+"""(Round 4: the production library takes these knobs as explicit alpine_debug_set_option calls; the environment variables below are read
+by the DIAGNOSTICS build only -- run with ALPINE_HIP_LIBRARY=alpine_amd/libalpine_hip_diag.so.)
+
+A/B of library knobs in ONE process, interleaved rounds (cdna_hip_programming.md rule 24): one engine per variant
 (each created under its own environment setting -- the library reads its knobs once, in alpine_create), same synthetic
 input, R rounds of `steps` iterations each, alternating between the variants.
 
