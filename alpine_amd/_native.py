@@ -55,7 +55,7 @@ class AlpineInfo(C.Structure):
         ("split_a", C.c_int32), ("split_b", C.c_int32), ("grid_a", C.c_int32), ("grid_b", C.c_int32),
         ("genes_padded", C.c_int64), ("cells_padded", C.c_int64),
         ("reduce_block_floats", C.c_int64), ("device_bytes", C.c_int64), ("x_sqnorm", C.c_double),
-        ("x_multi_plane_fraction", C.c_double), ("x3_wide", C.c_int32), ("reserved", C.c_int32),
+        ("x_multi_plane_fraction", C.c_double), ("x3_wide", C.c_int32), ("sweep_waves_per_simd", C.c_int32),
         ("span_rows_a", C.c_int32), ("span_rows_b", C.c_int32),
         ("spans_per_workgroup_a", C.c_int32), ("spans_per_workgroup_b", C.c_int32),
         ("xcd_bias_per_mille", C.c_int32), ("xcc_of_workgroup0", C.c_int32),

@@ -142,6 +142,8 @@ struct alpine_ctx {
     bool x3_narrow_pref = false;      // ... wanted for this shard size; alpine_finalize_X confirms it once the matrix instruction is known
     bool x3_narrow_forced = false;    // ... asked for explicitly (alpine_debug_set_option "x3_narrow"): kept whatever the matrix instruction
     double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
+    int x3_two_wave_opt = -1;         // alpine_debug_set_option "x3_two_wave": -1 = the library's choice, 0 = never, 1 = wherever the kernel exists
+    bool x3_two_wave = false;         // the K in (64, 128] sweeps run stream_gemm_x3v_kernel (two waves per SIMD; decided in alpine_finalize_X)
     bool x_one_plane = false;         // ... and NONE is (census of alpine_finalize_X): the K > 64 sweeps then run the form without split and zero-plane test
     bool team_ok = true;              // teams pay for this ctx's data and model size (decided in alpine_finalize_X; see team_width)
     // profiling
@@ -663,7 +665,7 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     info->x_sqnorm = c->xnorm2;
     info->x_multi_plane_fraction = c->x_multi_plane_frac;
     info->x3_wide = c->x3 && c->x3_wide ? 1 : 0;
-    info->reserved = 0;
+    info->sweep_waves_per_simd = !c->x3 ? 0 : (c->x3_two_wave ? 2 : 1);
     info->span_rows_a = c->geomA.L; info->span_rows_b = c->geomB.L;
     info->spans_per_workgroup_a = c->geomA.sub; info->spans_per_workgroup_b = c->geomB.sub;
     info->xcd_bias_per_mille = c->xcd_bias_pm; info->xcc_of_workgroup0 = c->xcc_of_wg0;
@@ -846,6 +848,14 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         const bool pad_tile = c->K <= c->KP - 16;
         // (K > 64 on one-plane data: x3w's one-plane form -- no split, no zero-plane test -- with or without a padding tile)
         c->x3_wide = c->x3_variant == 2 || (c->x3_variant < 0 && (c->x_multi_plane_frac > 0.01 || (pad_tile && c->KT >= 3) || (c->x_one_plane && c->KT >= 3)));
+        // K in (64, 128] on data that is NOT one-plane throughout: the two-waves-per-SIMD form of the 16x16x32 sweep (stream_gemm_x3v_kernel,
+        // kernels_x3.hpp).  tools/x3w_bench 60 (profiles/r04/x3v_bench_*.txt): full significands 3 - 10 % faster than x3w; in the
+        // library's iteration (tools/option_ab.py, engines interleaved, profiles/r04/option_ab_*.txt) cfg4's share on full significands
+        // 5.54 -> 5.25 ms, on one-plane counts level with x3w's one-plane form (3.50 / 3.53 vs 3.51 / 3.58 ms: inside the spread between
+        // two engines of the SAME kind), which therefore keeps its kernel.  x3_two_wave = 1 (option): the one-plane form of x3v as well.
+        c->x3_two_wave = c->x3 && !c->wide && c->KT >= 3 && !c->x3_ablate && c->x3_variant < 0 &&
+                         (c->x3_two_wave_opt == 1 || (c->x3_two_wave_opt < 0 && !c->x_one_plane));
+        if (c->x3_two_wave) c->x3_wide = true;
         const bool team_ok = c->KT >= 3 || c->x_multi_plane_frac <= 0.01;
         if (c->x3 && team_ok != c->team_ok) { c->team_ok = team_ok; apply_sweep_geometry(c, c->sweep_bf); c->tail_valid = false; }
         if (c->x3 && c->KT <= 2) {
@@ -1075,6 +1085,19 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
 #define X3W_PART(M_) case M_: hipLaunchKernelGGL((stream_gemm_x3w_kernel<4, 1, M_>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); break
             switch (active16) { X3W_PART(1); X3W_PART(2); X3W_PART(3); X3W_PART(4); X3W_PART(5); default: X3W_PART(6); }
 #undef X3W_PART
+            HIPCHK(c, hipGetLastError());
+            return 0;
+        }
+        if (c->x3_two_wave) {
+            const bool pad_tile = c->K <= c->KP - 16;                 // the last 16-component tile is all padding: not multiplied
+            const bool one_plane = c->x_one_plane;
+#define X3V_LAUNCH(KT_, M_) do { \
+                if (one_plane) hipLaunchKernelGGL((stream_gemm_x3v_kernel<KT_, 1, M_, true>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); \
+                else hipLaunchKernelGGL((stream_gemm_x3v_kernel<KT_, 1, M_, false>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); } while (0)
+            if (c->KT == 3) { if (pad_tile) X3V_LAUNCH(3, 5); else X3V_LAUNCH(3, 6); }
+            else if (c->KT == 4) { if (pad_tile) X3V_LAUNCH(4, 7); else X3V_LAUNCH(4, 8); }
+            else return fail(c, ALPINE_ERR_STATE, "internal: the two-wave sweep exists for 64 < K <= 128 only");
+#undef X3V_LAUNCH
             HIPCHK(c, hipGetLastError());
             return 0;
         }
@@ -2188,13 +2211,14 @@ extern "C" int alpine_debug_set_xcd_bias(alpine_ctx* c, int per_mille)
 //   "x3_variant" -1|0|2  matrix instruction of the x3 sweeps: 0 = 32x32x16, 2 = 16x16x32 general form, -1 = from the data; BEFORE alpine_finalize_X
 //   "wide_one_pass" 0|1  128 < K <= 256 on the x3 sweeps: one pass over X per sweep (default up to K = 224) or one per component half; BEFORE alpine_finalize_X
 //   "x3_narrow" 0|1      512-column workgroup tiles at K <= 64 (default: shards of <= 65 536 cells on the 32x32x16 form); BEFORE alpine_finalize_X
+//   "x3_two_wave" -1|0|1 64 < K <= 128 on the x3 sweeps: the two-waves-per-SIMD kernel (default) or the one-wave forms; BEFORE alpine_finalize_X
 extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int value)
 {
     if (!c || !name) return fail(c, ALPINE_ERR_BAD_ARG, "NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const std::string n(name);
-    const bool before_finalize = n == "x3_variant" || n == "x3_narrow" || n == "wide_one_pass";
+    const bool before_finalize = n == "x3_variant" || n == "x3_narrow" || n == "wide_one_pass" || n == "x3_two_wave";
     if (before_finalize && c->x_final) return fail(c, ALPINE_ERR_STATE, "option %s must be set before alpine_finalize_X", name);
     if (n == "no_tail") c->no_tail = value != 0 || c->unfused_mid;
     else if (n == "fused_w") c->fused_w = value != 0 && !c->unfused_mid;
@@ -2203,6 +2227,7 @@ extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int valu
     else if (n == "tail_stats_per_covariate") c->tail_stats_per_cov = value != 0;
     else if (n == "sg_variant") c->sg_variant = value;
     else if (n == "x3_variant") { if (value != -1 && value != 0 && value != 2) return fail(c, ALPINE_ERR_BAD_ARG, "x3_variant must be -1, 0 or 2"); c->x3_variant = value; }
+    else if (n == "x3_two_wave") { if (value < -1 || value > 1) return fail(c, ALPINE_ERR_BAD_ARG, "x3_two_wave must be -1, 0 or 1"); c->x3_two_wave_opt = value; }
     else if (n == "wide_one_pass") {
         if (!c->wide || !c->x3 || c->x3_ablate) return 0;     // only wide models on the x3 sweeps have the two forms
         c->wide_one_pass = value != 0;

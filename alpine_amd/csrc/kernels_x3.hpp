@@ -564,6 +564,223 @@ void stream_gemm_x3w_kernel(const float* __restrict__ S, const float* __restrict
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
+// The x3w sweep with TWO waves per SIMD ("x3v", round 4): 8 waves per workgroup, a wave owns ONE 64-column group x all KP components
+// (M16A x 4 accumulator tiles: 112 registers at K = 105), 256 registers per wave.  Why: on X with full significands one wave per SIMD
+// executes the split of a tile (47 vector instructions), its 42 MFMAs and the zero-plane branch strictly one after the other -- the
+// matrix pipe idles 40 % of the time (profiles/r04/cfg4_x3_share8_fullsig_*), and neither the compiler's interleave nor a pinned one
+// (x3p, removed) hides vector work in the MFMA gaps of a SINGLE wave.  Two waves do it by themselves: while one wave splits, the other
+// wave's MFMAs issue (tools/inflight_bw.hip, TWO=1: the sweep's skeleton 3.64 -> 5.14 TB/s).  Same workgroup tile (512 columns), same
+// stream-K division and pieces as stream_gemm_x3w_kernel<KT, 1, M16A>; per accumulator the same products in the same order (stages
+// ascending; hi x {hi, mid, lo}, mid x {hi, mid}, lo x hi), so the pieces are bitwise those of x3w on data where the zero-plane
+// decision -- here one per 64-column group and stage, there one per 16-column tile -- adds nothing but exact zeros (non-negative X).
+// Structure of a stage as in x3w2 below: the four column tiles are split up front, which frees the X registers -- the group's 8 loads
+// are re-issued for the next stage BEFORE the stage's MFMAs -- then component tile by component tile: 3 ds_read_b128 (one tile ahead),
+// 12 or 24 MFMAs.  The panel is staged as in x3w (float32 master -> registers -> split -> LDS, one 8-row set per thread and stage).
+template <int KT, int NG = 1, int M16A = 2 * KT, bool ONEPLANE = false>
+__global__ __launch_bounds__(512, 1)
+void stream_gemm_x3v_kernel(const float* __restrict__ S, const float* __restrict__ Pf, float* __restrict__ pieces,
+                            int64_t ldS, SweepGeom g, int* __restrict__ xcc_out)
+{
+    sg_report_xcc(xcc_out);
+    static_assert(M16A >= 1 && M16A <= 2 * KT, "active 16-component tiles");
+    static_assert(M16A * NG <= 8, "128 accumulator registers per lane");
+    constexpr int KP = 32 * KT, M16 = 2 * KT, KPA = 16 * M16A;       // KPA: panel components that are staged and multiplied
+    constexpr int WAVE_F = 64 * NG, NW = 8, BLOCK_F = NW * WAVE_F;   // NG 64-column groups per wave (K <= 64: 2 -> 1024-column workgroup tiles)
+    constexpr int NT = 64 * NW;
+    constexpr int ROWS = 32;
+    static_assert(SG_ROW_ALIGN % ROWS == 0, "stream-K spans are multiples of one stage");
+    constexpr int STAGE_BF16 = ROWS * KP;
+    constexpr int SETS = (ROWS / 8) * KP;
+    static_assert(SETS <= NT && 2 * SETS >= NT, "one 8-row set of the panel per thread and stage");
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * STAGE_BF16];
+    __shared__ __attribute__((aligned(16))) float flush_tr[NW][16 * (KP + 4)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kg = lane >> 4;
+    SgWalk walk;
+    int team, member;
+    sg_team_of_block(g, blockIdx.x, team, member);
+    sg_walk_init(walk, g, team);
+
+    // this thread's set of a panel stage: rows 8 p_rb .. + 7 of component p_col.  EVERY thread loads a set (those past the last set
+    // re-load an earlier one and do not store it): a load under a condition would make the compiler wait for ALL outstanding loads
+    // at the join -- the X split would then wait for the panel loads issued just before it, a full memory latency per stage
+    const int p_set = tid < SETS ? tid : tid - SETS;
+    const int p_rb = p_set / KP, p_col = p_set % KP;
+    const bool p_mine = tid < SETS && p_col < KPA;        // (the padding components are loaded -- zeros -- but neither stored nor read)
+    float pf[8];
+    f32x4 x[8];                                           // ONE 64-column group x 32 rows in flight per wave (two waves per SIMD: 64 KiB per CU)
+
+    int ft, r_begin, r_end;
+    int64_t slot;
+    while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
+        const int nst = (r_end - r_begin) / ROWS;
+        const int wt = ft * g.gw + member;                 // this workgroup's BLOCK_F-wide tile (ft = the team's tile)
+        if ((int64_t)wt * BLOCK_F >= g.F) continue;        // a member past the last column of a partly filled team tile (block-uniform)
+        const int f0 = wt * BLOCK_F + wave * WAVE_F;       // (F is a multiple of 128: a wave's columns are all inside or all outside)
+        const bool active = f0 < g.F;
+
+        const float* pfptr = Pf + (int64_t)(r_begin + 8 * p_rb) * KP + p_col;
+        auto load_p = [&](int t) {
+            const float* src = pfptr + (int64_t)t * ROWS * KP;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = src[e * KP];
+        };
+        auto store_p = [&](int b) {
+            if (p_mine) {
+                u32x4 o[3];
+                x3_split8_scalar(pf, o);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&lds[b][q * STAGE_BF16 + 8 * p_set]) = o[q];
+            }
+        };
+
+        __syncthreads();
+        load_p(0);
+        store_p(0);
+        if (nst > 1) load_p(1);
+
+        if (!active) {
+            // a wave whose columns lie past F: the panel staging and EVERY barrier of the loop below, nothing else
+            __syncthreads();
+            for (int t = 0; t + 1 < nst; ++t) {
+                store_p((t + 1) & 1);
+                if (t + 2 < nst) load_p(t + 2);
+                __syncthreads();
+            }
+            continue;
+        }
+
+        f32x4 acc[M16A][4 * NG];                            // (only the tiles with real components; the others are flushed as zeros)
+#pragma unroll
+        for (int m = 0; m < M16A; ++m)
+#pragma unroll
+            for (int j = 0; j < 4 * NG; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // this lane's float4 of row r_begin + 8 kg (+ e), columns f0 + 64 group + 4 c16 .. + 3 (element j -> column tile j, column c16):
+        // a wave-uniform row address (scalar registers, scalar arithmetic) + ONE 32-bit lane offset -- the saddr form of global_load;
+        // per-lane 64-bit addresses of 8 rows x NG groups, which the compiler hoists out of the stage loop, cost 16+ registers of the 256
+        const char* xrow0 = reinterpret_cast<const char*>(S + (int64_t)r_begin * ldS + f0);
+        const unsigned x_lane = (unsigned)((int64_t)(8 * kg) * ldS + 4 * c16) * 4u;          // < 2^32: 24 rows of at most 2^25 floats
+        auto load_x = [&](int t, int cg) {
+            typedef const __attribute__((address_space(1))) char* gchar_p;
+            typedef const __attribute__((address_space(1))) f32x4* gf32x4_p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned long long row = reinterpret_cast<unsigned long long>(xrow0 + (((int64_t)t * ROWS + e) * ldS + 64 * cg) * 4);
+                const unsigned long long urow = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(row >> 32)) << 32)
+                                                | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)row);      // (wave-uniform by construction: into scalar registers)
+                unsigned lane_off = x_lane;
+                asm volatile("" : "+v"(lane_off));          // (opaque: keeps the compiler from folding the lane offset into a hoisted per-lane 64-bit base)
+                x[e] = __builtin_nontemporal_load(reinterpret_cast<gf32x4_p>(reinterpret_cast<gchar_p>(urow) + lane_off));
+            }
+        };
+        const int lds_lane = (kg * KP + c16) * 8;
+
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+
+        // one stage, group by group: split the group's four column tiles (which frees the X registers), re-issue the 8 loads for the
+        // NEXT group-stage, then component tile by component tile: 3 ds_read_b128 (one tile ahead), 12 or 24 MFMAs
+        auto stage = [&](const unsigned short* __restrict__ lrow, int t_next, bool last) {
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) {
+                u32x4 b[4][3];
+                unsigned rest = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = x[e][j];
+                    if constexpr (ONEPLANE) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b[j][0][q] = x3_cvt2(v[2 * q], v[2 * q + 1]);       // exact: every value is one bf16 plane
+                        b[j][1] = b[j][2] = u32x4{0u, 0u, 0u, 0u};
+                    } else {
+                        x3_split8_scalar(v, b[j]);
+                        rest |= b[j][1][0] | b[j][1][1] | b[j][1][2] | b[j][1][3];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (cg + 1 < NG) load_x(t_next - 1, cg + 1);
+                else if (!last) load_x(t_next, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                auto lda = [&](int m, u32x4 (&a)[3]) {
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp) a[pp] = *reinterpret_cast<const u32x4*>(lrow + pp * STAGE_BF16 + (16 * m) * 8);
+                };
+                // (the fragments of the next component tile are read one tile ahead where the registers allow it: 128 accumulators leave
+                // no room for the second set -- the other wave of the SIMD covers the LDS latency there)
+                constexpr bool AHEAD = M16A * NG < 8;
+                u32x4 a[AHEAD ? 2 : 1][3];
+                lda(0, a[0]);
+                // (an if-THEN per component tile, not two copies of the loop: see stream_gemm_x3w2_kernel)
+                const bool full = !ONEPLANE && __builtin_amdgcn_ballot_w64((rest & 0x7fff7fffu) != 0u) != 0ull;
+#pragma unroll
+                for (int m = 0; m < M16A; ++m) {
+                    asm volatile("" ::: "memory");
+                    if (AHEAD && m + 1 < M16A) lda(m + 1, a[AHEAD ? (m + 1) & 1 : 0]);
+                    if (!AHEAD && m > 0) lda(m, a[0]);
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[m][4 * cg + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[AHEAD ? m & 1 : 0][pp]), __builtin_bit_cast(bf16x8, b[j][0]), acc[m][4 * cg + j], 0, 0, 0);
+                    if (full) {
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[m][4 * cg + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[AHEAD ? m & 1 : 0][pp]), __builtin_bit_cast(bf16x8, b[j][1]), acc[m][4 * cg + j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[m][4 * cg + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[AHEAD ? m & 1 : 0][0]), __builtin_bit_cast(bf16x8, b[j][2]), acc[m][4 * cg + j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+
+        // (t_next is the stage whose FIRST group the last group of this stage re-issues; the other groups of a stage re-issue within
+        // stage t_next - 1 = this stage)
+        int t = 0;
+        for (; t + 2 < nst; ++t) {
+            store_p((t + 1) & 1);
+            load_p(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(&lds[t & 1][lds_lane], t + 1, false);
+            __syncthreads();
+        }
+        if (t + 1 < nst) {
+            store_p((t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(&lds[t & 1][lds_lane], t + 1, false);
+            __syncthreads();
+            ++t;
+        }
+        stage(&lds[t & 1][lds_lane], t + 1, true);
+
+        // D: component = 16 m + 4 kg + e, column = c16 -> f_local = WAVE_F * wave + 64 group + 4 c16 + tile
+        float* out = pieces + (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KP;
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 d[M16];
+#pragma unroll
+                for (int m = 0; m < M16; ++m) d[m] = m < M16A ? acc[m < M16A ? m : 0][4 * cg + tt] : f32x4{0.f, 0.f, 0.f, 0.f};
+                sg_flush_tile16<KT>(flush_tr[wave], d, out + (int64_t)(64 * cg + tt) * KP, 4 * KP, lane);
+            }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
 // One pass over X for 128 < K <= 256 ("x3w2", round 4).  The blocked two-half path of kernels_wide.hpp ran every sweep TWICE, once per
 // half of the components (X read four times per iteration: 0.32 of the HBM roof at K = 150).  Here a wave owns 64 columns x ALL 256
 // components -- 16 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 256 registers -- and a workgroup 256 columns, so X is read

@@ -584,6 +584,8 @@ def main():
             kname, kdesc = "stream_gemm_kernel", "MFMA f32 32x32x2"
         elif one_pass:
             kname, kdesc = "stream_gemm_x3w2_kernel", "one pass over X for 128 < K <= 256: float32 X split into exact bf16 planes in registers, MFMA bf16 16x16x32"
+        elif dtype == "x3" and info.sweep_waves_per_simd == 2:
+            kname, kdesc = "stream_gemm_x3v_kernel", "64 < K <= 128, two waves per SIMD: float32 X split into exact bf16 planes in registers, MFMA bf16 16x16x32"
         elif dtype == "x3" and info.x3_wide:
             kname, kdesc = "stream_gemm_x3w_kernel", "float32 X split into exact bf16 planes in registers, MFMA bf16 16x16x32"
         elif dtype == "x3":
@@ -609,7 +611,7 @@ def main():
             "tflops": ach_tf, "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS,
             "sweep_launches_per_step": 2 * passes,
             "sweeps_share_of_step": (passes * (m["ms_a"] / max(1, m["n_a"]) + m["ms_b"] / max(1, m["n_b"])) / (1e3 * m["dt"] / args.steps)) if m["dt"] > 0 else 0.0,
-            "x3_wide": int(info.x3_wide), "x_multi_plane_fraction": float(info.x_multi_plane_fraction),
+            "x3_wide": int(info.x3_wide), "sweep_waves_per_simd": int(info.sweep_waves_per_simd), "x_multi_plane_fraction": float(info.x_multi_plane_fraction),
             "accumulation_span_rows": [int(info.span_rows_a), int(info.span_rows_b)],
         }
 

@@ -120,7 +120,8 @@ typedef struct {
     double x_sqnorm;                /* ||X_local||_F^2 (valid after alpine_finalize_X) */
     double x_multi_plane_fraction;  /* fraction of the elements of X that are not exactly one bf16 plane (float32 storage; after alpine_finalize_X) */
     int32_t x3_wide;                /* 1: the x3 sweeps run on v_mfma_f32_16x16x32_bf16 (full-significand data), 0: on 32x32x16 (count-like data) */
-    int32_t reserved;
+    int32_t sweep_waves_per_simd;   /* x3 sweeps: 2 = stream_gemm_x3v_kernel (64 < K <= 128: 8 waves per workgroup, 256 registers each), 1 = the
+                                       one-wave-per-SIMD forms, 0 = not an x3 ctx (was `reserved`, always 0, before round 4) */
     int32_t span_rows_a, span_rows_b;                      /* contraction rows one float32 accumulator chain covers (<= ALPINE_MAX_ACCUMULATION_ROWS) */
     int32_t spans_per_workgroup_a, spans_per_workgroup_b;  /* accumulator restarts + 1 of a sweep workgroup (1 at BASELINE config 3) */
     int32_t xcd_bias_per_mille;     /* spans of even sweep workgroups are this much longer (negative: shorter) than the mean, odd ones the opposite */

@@ -976,10 +976,12 @@ def test_team_width_is_chosen_from_the_shape_and_the_data():
     """The library's own choice (alpine_info.team_width_*): the widest of 8 / 4 / 2 that leaves at most 2.5 % of the members idle, 1 where
     teams do not pay (K <= 64 on data with full significands), never for forced divisions or the float32-MFMA sweeps."""
     nat = _native()
-    def widths(G, N, K, x_dtype="x3", fullsig=False, **kw):
+    def widths(G, N, K, x_dtype="x3", fullsig=False, options=None, **kw):
         rng = np.random.default_rng(0)
         X = rng.gamma(0.3, 3.0, size=(N, G)).astype(np.float32) if fullsig else rng.poisson(1.0, size=(N, G)).astype(np.float32)
         eng = nat.NativeShard(n_genes=G, n_cells=N, n_components=K, cov_components=[], cov_levels=[], lam=[], x_dtype=x_dtype, **kw)
+        for k, v in (options or {}).items():
+            eng.debug_set_option(k, v)
         eng.upload_X_host(X)
         eng.finalize_X()
         info = eng.info()
@@ -988,7 +990,9 @@ def test_team_width_is_chosen_from_the_shape_and_the_data():
     # 4096 genes = 8 tiles of 512 -> 8; 70 000 cells -> 69 tiles of 1024 (K <= 64, > 65 536 cells) -> 72 with 8 (4 % idle) no, 4 (72: no) -> 2 (70: 1.4 %)
     assert widths(4096, 2048, 20) == (8, 4)                       # narrow tiles (small shard): 8 of 8, 4 of 4
     assert widths(4096, 2048, 20, fullsig=True) == (1, 1)         # K <= 64 on full significands: no teams
-    assert widths(4096, 2048, 100, fullsig=True) == (8, 4)        # K > 64: teams whatever the data
+    assert widths(4096, 2048, 100) == (8, 4)                      # K > 64: teams whatever the data and the kernel
+    assert widths(4096, 2048, 100, fullsig=True) == (8, 4)
+    assert widths(4096, 2048, 100, fullsig=True, options={"x3_two_wave": 0}) == (8, 4)
     assert widths(4096, 2048, 20, x_dtype="f32") == (1, 1)
     assert widths(4096, 2048, 20, split_a=2, split_b=2) == (1, 1)
 
@@ -1001,15 +1005,19 @@ def test_one_plane_form_of_the_wide_sweeps_is_bitwise_the_general_form(name, K):
     plane must switch the census back."""
     c = _count_like(load_case(name), 6.0)
     assert float(c.X.max()) < 256
-    a = make_engine(c, x_dtype="x3")
-    assert a.info().x_multi_plane_fraction == 0.0 and a.info().x3_wide == 1
-    b = make_engine(c, x_dtype="x3", options={"x3_variant": 2})
-    for e in (a, b):
+    a = make_engine(c, x_dtype="x3")                                   # the library's choice: x3w, one-plane form
+    assert a.info().x_multi_plane_fraction == 0.0 and a.info().x3_wide == 1 and a.info().sweep_waves_per_simd == 1
+    b = make_engine(c, x_dtype="x3", options={"x3_variant": 2})        # x3w, general form
+    d1 = make_engine(c, x_dtype="x3", options={"x3_two_wave": 1})      # x3v (two waves per SIMD), one-plane form
+    assert b.info().sweep_waves_per_simd == 1 and d1.info().sweep_waves_per_simd == 2
+    for e in (a, b, d1):
         e.run(4, with_loss=True)
-    (Wa, Ha, Ba), (Wb, Hb, Bb) = a.get_factors(), b.get_factors()
+    (Wa, Ha, Ba), (Wb, Hb, Bb), (Wd, Hd, Bd) = a.get_factors(), b.get_factors(), d1.get_factors()
     assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb) and np.array_equal(a.losses(), b.losses())
+    assert np.array_equal(Wa, Wd) and np.array_equal(Ha, Hd) and np.array_equal(a.losses(), d1.losses())
     a.close()
     b.close()
+    d1.close()
     c.X = c.X.copy()
     c.X[3, 5] = 257.0                                   # two planes
     d = make_engine(c, x_dtype="x3")
@@ -1020,6 +1028,41 @@ def test_one_plane_form_of_the_wide_sweeps_is_bitwise_the_general_form(name, K):
     assert rel_fro(d.get_factors()[0], f.get_factors()[0]) < 2e-5
     d.close()
     f.close()
+
+
+@pytest.mark.parametrize("name", ["k105", "k74", "guided_wide"])
+@pytest.mark.parametrize("data", ["golden", "counts_with_a_few_two_plane_values"])
+def test_two_wave_sweeps_are_bitwise_the_one_wave_form(name, data):
+    """64 < K <= 128: stream_gemm_x3v_kernel (8 waves per workgroup, two per SIMD, a wave = 64 columns x all components; the library's choice
+    on data that is not one-plane throughout) against stream_gemm_x3w_kernel (4 waves, 128 columns each): same workgroup tile, same division, same pieces, and per accumulator the same
+    products in the same order -- the zero-plane decision is per 64-column group there and per 16-column tile here, which on non-negative X
+    only adds exact zeros.  So the two must agree BITWISE, on full significands (the golden cases: gamma-distributed X) and on count data
+    where most tiles skip the mid / lo products and a few do not; and both meet the reference tolerances on the golden input."""
+    c = load_case(name)
+    if data != "golden":
+        c = _count_like(c, 6.0)
+        c.X = c.X.copy()
+        rng = np.random.default_rng(5)
+        idx = rng.integers(0, c.X.size, size=40)
+        c.X.reshape(-1)[idx] = rng.uniform(0.5, 300.0, size=40).astype(np.float32)      # two / three planes, scattered
+    a = make_engine(c, x_dtype="x3")
+    b = make_engine(c, x_dtype="x3", options={"x3_two_wave": 0})
+    ia, ib = a.info(), b.info()
+    assert ia.sweep_waves_per_simd == 2 and ib.sweep_waves_per_simd == 1 and ia.x3_wide == 1
+    assert 0 < ia.x_multi_plane_fraction
+    if ib.x3_wide != 1:                                    # (count-like data without a padding tile would take the 32x32x16 form: a different order)
+        b.close()
+        b = make_engine(c, x_dtype="x3", options={"x3_two_wave": 0, "x3_variant": 2})
+    for e in (a, b):
+        e.debug_set_team_width(1)                          # (the library's widths differ between the two forms: same division for the comparison)
+        e.run(c.T, with_loss=True)
+    (Wa, Ha, Ba), (Wb, Hb, Bb) = a.get_factors(), b.get_factors()
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb) and np.array_equal(a.losses(), b.losses())
+    if data == "golden":
+        assert rel_fro(Wa, c.WT_unscaled) < 1e-4 and rel_fro(Ha, c.HT_unscaled) < 1e-4
+        assert_loss_rows_close(a.losses(), c.loss_history, n_cells=c.X.shape[0])
+    a.close()
+    b.close()
 
 
 @pytest.mark.parametrize("name", ["wide_k150", "wide_k200_fro", "als_wide_k160_fro", "mb_wide_k150"])

@@ -219,12 +219,121 @@ void run(const float* x, long ld, int rows_total, float* out)
            bytes / (best * 1e-3) / 1e12);
 }
 
+// TWO waves per SIMD (round 4, second half): 8 waves per workgroup, a wave owns ONE 64-column group x 7 component tiles (112 accumulator
+// registers), D group-stages (32 rows each) of its group in flight; 256 registers per wave.  The question: does the hardware's own
+// interleave of two waves hide the split's vector work behind the other wave's MFMAs (which pinning the schedule of ONE wave did not)?
+template <int D, int NM, int SPLIT = 0>
+__global__ __launch_bounds__(512, 1) void rd2(const float* __restrict__ S, long ldS, int n_tiles, int rows_total, int rows_per_wg, float* out)
+{
+    const long span0 = (long)blockIdx.x * rows_per_wg;
+    const int tile = (int)(span0 / rows_total);
+    const int r0 = (int)(span0 % rows_total);
+    if (tile >= n_tiles) return;
+    const int r1 = min(rows_total, r0 + rows_per_wg);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, kg = lane >> 4;
+    const int nu = (r1 - r0) / 32;                               // group-stages of this wave's group
+    auto addr = [&](int u, int e) { return S + (long)(r0 + 32 * u + 8 * kg + e) * ldS + tile * 512 + wave * 64 + 4 * c16; };
+    f32x4 x[D][8];
+    f32x4 acc[7][4];
+#pragma unroll
+    for (int m = 0; m < 7; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[m][i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[d][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(addr(d < nu ? d : 0, e)));
+    for (int u0 = 0; u0 < nu; u0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int u = u0 + d;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (SPLIT == 0) {
+                    u32x4 b;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = __float_as_uint(x[d][2 * q][t]) ^ (__float_as_uint(x[d][2 * q + 1][t]) >> 16);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m)
+                        acc[m % 7][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, b), acc[m % 7][t], 0, 0, 0);
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = x[d][e][t];
+                    u32x4 b[3];
+                    split8(v, b);
+                    const unsigned rest = (b[1][0] | b[1][1] | b[1][2] | b[1][3]) & 0x7fff7fffu;
+                    if constexpr (SPLIT == 1) {
+                        acc[6][t][0] += __uint_as_float(rest | b[2][0] | b[2][1] | b[2][2] | b[2][3]);
+#pragma unroll
+                        for (int m = 0; m < NM; ++m)
+                            acc[m % 7][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[0]), __builtin_bit_cast(bf16x8, b[0]), acc[m % 7][t], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < NM / 2; ++m)
+                            acc[m % 7][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[0]), __builtin_bit_cast(bf16x8, b[0]), acc[m % 7][t], 0, 0, 0);
+                        if (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {
+#pragma unroll
+                            for (int m = 0; m < NM / 2; ++m)
+                                acc[m % 7][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[m < 14 ? 1 : 2]), __builtin_bit_cast(bf16x8, b[0]), acc[m % 7][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int un = u + D < nu ? u + D : u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[d][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(addr(un, e)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int m = 0; m < 7; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[m][i][0] + acc[m][i][1] + acc[m][i][2] + acc[m][i][3];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s += x[d][0][0];
+    if (s == 12345.f) out[blockIdx.x] = s;
+}
+
+template <int D, int NM, int SPLIT = 0>
+void run2(const float* x, long ld, int rows_total, float* out)
+{
+    const int n_tiles = (int)(ld / 512), grid = 256;
+    const long total = (long)n_tiles * rows_total;
+    int rows_per_wg = (int)((total + grid - 1) / grid);
+    rows_per_wg = (rows_per_wg + 32 * D - 1) / (32 * D) * (32 * D);
+    const int g = (int)((total + rows_per_wg - 1) / rows_per_wg);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((rd2<D, NM, SPLIT>), dim3(g), dim3(512), 0, 0, x, ld, n_tiles, rows_total, rows_per_wg, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (rep > 0 && ms < best) best = ms;
+    }
+    const double bytes = (double)n_tiles * 512 * 4.0 * rows_total;
+    printf("TWO WAVES PER SIMD split=%d D=%d group-stages (%2d KiB per wave, %3d per CU) in flight, %2d MFMAs per tile: ld=%6ld rows=%6d grid=%3d  %.3f ms  %.2f TB/s\n", SPLIT, D, 8 * D, 64 * D, NM, ld, rows_total, g, best,
+           bytes / (best * 1e-3) / 1e12);
+}
+
+__global__ void fill_random(float* __restrict__ x, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761ull) ^ 12345u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        x[i] = (float)(h >> 8) * (1.0f / 16777216.0f) * 3.7f;
+    }
+}
+
 int main()
 {
     const size_t bytes = (size_t)11 << 30;
     float* x; float* out;
     hipMalloc(&x, bytes); hipMalloc(&out, 1 << 20);
-    hipMemset(x, std::getenv("ONEPLANE") ? 0 : 0x3c, bytes);   // 0x3c3c3c3c = 0.0115 (three non-zero planes); ONEPLANE=1: zeros (the zero-plane test passes)
+    hipMemset(x, std::getenv("ONEPLANE") ? 0 : 0x3c, bytes);
+    // RANDOMX=1: full 24-bit significands, every value different (the constant fill toggles few bits in the matrix pipe: a higher clock)
+    if (std::getenv("RANDOMX")) hipLaunchKernelGGL(fill_random, dim3(8192), dim3(256), 0, 0, x, bytes / 4);   // 0x3c3c3c3c = 0.0115 (three non-zero planes); ONEPLANE=1: zeros (the zero-plane test passes)
     // cfg4's per-GPU share: X_gn = 20096 rows x 125056 cols (W^TX sweep), X_ng = 125056 rows x 20096 cols (XH^T sweep)
     for (int pass = 1; pass < 2; ++pass) {       // (pass 0 -- spans that cross a tile are cut at the tile's end: its byte count is wrong)
         const long ld = pass == 0 ? 125056 - 125056 % 512 : 20096 - 20096 % 512;
@@ -234,6 +343,17 @@ int main()
         run<2, 42>(x, ld, rows, out); run<3, 42>(x, ld, rows, out); run<4, 42>(x, ld, rows, out);
         run<2, 21, 1>(x, ld, rows, out); run<3, 21, 1>(x, ld, rows, out); run<2, 42, 1>(x, ld, rows, out);
         run<2, 42, 2>(x, ld, rows, out); run<3, 42, 2>(x, ld, rows, out);
+        if (std::getenv("TWO")) {
+            for (int again = 0; again < 2; ++again) {
+                run2<1, 0>(x, ld, rows, out); run2<2, 0>(x, ld, rows, out); run2<3, 0>(x, ld, rows, out);
+                run2<1, 42>(x, ld, rows, out); run2<2, 42>(x, ld, rows, out); run2<3, 42>(x, ld, rows, out);
+                run2<1, 42, 1>(x, ld, rows, out); run2<2, 42, 1>(x, ld, rows, out); run2<3, 42, 1>(x, ld, rows, out);
+                run2<1, 42, 2>(x, ld, rows, out); run2<2, 42, 2>(x, ld, rows, out); run2<3, 42, 2>(x, ld, rows, out);
+                run2<2, 21>(x, ld, rows, out); run2<2, 21, 1>(x, ld, rows, out);
+                run<2, 42>(x, ld, rows, out); run<2, 42, 1>(x, ld, rows, out); run<2, 42, 2>(x, ld, rows, out);
+            }
+            continue;
+        }
         run<2, 42, 3, 2, 8>(x, ld, rows, out); run<3, 42, 3, 2, 8>(x, ld, rows, out);
         run<2, 42, 3, 3, 8>(x, ld, rows, out); run<2, 42, 3, 2, 4>(x, ld, rows, out); run<2, 42, 3, 2, 100>(x, ld, rows, out); run<2, 42, 3, 1, 100>(x, ld, rows, out);
     }

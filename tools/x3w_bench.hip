@@ -23,7 +23,7 @@ __global__ void fill_kernel(float* __restrict__ x, size_t n, int mode, unsigned 
     }
 }
 
-struct Variant { const char* name; int kind; int gw; };     // kind 0 = x3w, 1 = x3 (32x32x16), 2 = x3w one-plane
+struct Variant { const char* name; int kind; int gw; };     // kind 0 = x3w, 1 = x3 (32x32x16), 2 = x3w one-plane, 3 = x3w no test, 4 = x3v (two waves per SIMD), 5 = x3v one-plane
 
 template <int KT, int NH, int M16A>
 static void launch_once(const Variant& v, const float* S, const float* P, float* pieces, int64_t ldS, const SweepGeom& g)
@@ -33,7 +33,15 @@ static void launch_once(const Variant& v, const float* S, const float* P, float*
         case 0: hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT, NH, M16A, false>), ARGS); break;
         case 1: hipLaunchKernelGGL((stream_gemm_x3_kernel<KT, NH>), ARGS); break;
         case 3: hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT, NH, M16A, false, true>), ARGS); break;
-        default: hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT, NH, M16A, true>), ARGS); break;
+        case 2: hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT, NH, M16A, true>), ARGS); break;
+        default:
+            if constexpr (M16A * NH <= 8) {           // the two-waves-per-SIMD form
+#define ARGS8 dim3(sg_grid(g)), dim3(512), 0, 0, S, P, pieces, ldS, g, (int*)nullptr
+                if (v.kind == 4) hipLaunchKernelGGL((stream_gemm_x3v_kernel<KT, NH, M16A, false>), ARGS8);
+                else hipLaunchKernelGGL((stream_gemm_x3v_kernel<KT, NH, M16A, true>), ARGS8);
+#undef ARGS8
+            }
+            break;
     }
 #undef ARGS
 }
@@ -56,7 +64,7 @@ static void shape(int64_t G, int64_t N, float* X, float* P, float* pieces, size_
                    orient == 0 ? "W^TX" : "XH^T");
             std::vector<Variant> variants; std::vector<SweepGeom> geoms; std::vector<double> rel;
             for (const Variant& v : all) {
-                if (v.kind == 2 && data != 0) continue;
+                if ((v.kind == 2 || v.kind == 5) && data != 0) continue;
                 if (v.kind == 3 && data != 1) continue;
                 if (256 % (8 * v.gw) != 0 && v.gw != 1) continue;
                 const SweepGeom g = sg_make_geom(F, R, 256 / v.gw, 0, BF * v.gw, 0, v.gw);
@@ -120,6 +128,26 @@ int main(int argc, char** argv)
         shape<4, 1, 7>(G, 125056, X, P, pieces, piece_floats, out, ref, reps,
                        {{"x3w (round 3)", 0, 1}, {"x3w teams of 2", 0, 2}, {"x3w teams of 4", 0, 4}, {"x3w teams of 8", 0, 8}, {"x3w teams of 16", 0, 16}, {"x3w teams of 32", 0, 32},
                         {"x3w one-plane", 2, 1}, {"x3w one-plane teams of 8", 2, 8}, {"x3w no test", 3, 1}, {"x3w no test teams of 8", 3, 8}, {"x3w (again)", 0, 1}});
+    if (which & 4)      // K = 105 again: the two-waves-per-SIMD form against x3w
+        shape<4, 1, 7>(G, 125056, X, P, pieces, piece_floats, out, ref, reps,
+                       {{"x3w", 0, 1}, {"x3w teams of 8", 0, 8}, {"x3v", 4, 1}, {"x3v teams of 2", 4, 2}, {"x3v teams of 4", 4, 4}, {"x3v teams of 8", 4, 8},
+                        {"x3w one-plane teams of 8", 2, 8}, {"x3v one-plane", 5, 1}, {"x3v one-plane teams of 8", 5, 8}, {"x3w (again)", 0, 1}});
+    if (which & 8)      // K = 60 again: the two-waves-per-SIMD form against x3 / x3w
+        shape<2, 2, 4>(G, 200064, X, P, pieces, piece_floats, out, ref, reps,
+                       {{"x3w", 0, 1}, {"x3 (32x32x16)", 1, 1}, {"x3 teams of 8", 1, 8}, {"x3v", 4, 1}, {"x3v teams of 2", 4, 2}, {"x3v teams of 4", 4, 4}, {"x3v teams of 8", 4, 8},
+                        {"x3v one-plane", 5, 1}, {"x3v one-plane teams of 4", 5, 4}, {"x3v one-plane teams of 8", 5, 8}, {"x3w (again)", 0, 1}});
+    if (which & 16)     // K = 128 (no padding tile) and K = 96 / 80 (three 32-component tiles): x3 (32x32x16) / x3w / x3v
+        shape<4, 1, 8>(G, 125056, X, P, pieces, piece_floats, out, ref, reps,
+                       {{"x3w", 0, 1}, {"x3 (32x32x16)", 1, 1}, {"x3 teams of 8", 1, 8}, {"x3w teams of 8", 0, 8}, {"x3v", 4, 1}, {"x3v teams of 2", 4, 2}, {"x3v teams of 8", 4, 8},
+                        {"x3w one-plane teams of 8", 2, 8}, {"x3v one-plane teams of 8", 5, 8}, {"x3w (again)", 0, 1}});
+    if (which & 32) {
+        shape<3, 1, 6>(G, 125056, X, P, pieces, piece_floats, out, ref, reps,
+                       {{"x3w", 0, 1}, {"x3 (32x32x16)", 1, 1}, {"x3 teams of 8", 1, 8}, {"x3w teams of 8", 0, 8}, {"x3v", 4, 1}, {"x3v teams of 2", 4, 2}, {"x3v teams of 8", 4, 8},
+                        {"x3w one-plane teams of 8", 2, 8}, {"x3v one-plane teams of 8", 5, 8}, {"x3w (again)", 0, 1}});
+        shape<3, 1, 5>(G, 125056, X, P, pieces, piece_floats, out, ref, reps,
+                       {{"x3w", 0, 1}, {"x3w teams of 8", 0, 8}, {"x3v", 4, 1}, {"x3v teams of 2", 4, 2}, {"x3v teams of 8", 4, 8},
+                        {"x3w one-plane teams of 8", 2, 8}, {"x3v one-plane teams of 8", 5, 8}, {"x3w (again)", 0, 1}});
+    }
     if (which & 2)      // BASELINE config 3: K = 60
         shape<2, 2, 4>(G, 200064, X, P, pieces, piece_floats, out, ref, reps,
                        {{"x3 (round 3)", 1, 1}, {"x3 teams of 2", 1, 2}, {"x3 teams of 4", 1, 4}, {"x3 teams of 8", 1, 8}, {"x3 teams of 16", 1, 16},
