@@ -262,7 +262,8 @@ int alpine_debug_set_xcd_bias(alpine_ctx* ctx, int per_mille);
 /* Diagnostics / tests: the result-preserving knobs of the library (other kernels or launch structure, same factors up to summation
  * order) as explicit calls; the production library reads NONE of them from the environment (it reads ALPINE_HIP_GUARD, ALPINE_HIP_LDS_LIMIT
  * and ALPINE_HIP_XCD_BIAS only).  Names: "no_tail", "fused_w", "unfused_mid", "guided_scalar", "tail_stats_per_covariate", "sg_variant",
- * and -- before alpine_finalize_X -- "x3_variant" (-1 | 0 | 2), "x3_narrow" (0 | 1) and "wide_one_pass" (0 | 1). */
+ * and -- before alpine_finalize_X -- "x3_variant" (-1 | 0 | 2), "x3_narrow" (0 | 1), "wide_one_pass" (0 | 1) and "x3_two_wave" (-1 | 0 | 1:
+ * 64 < K <= 128, the two-waves-per-SIMD sweep; -1 = for data with more than one bf16 plane, alpine_info.sweep_waves_per_simd reports it). */
 int alpine_debug_set_option(alpine_ctx* ctx, const char* name, int value);
 /* Diagnostics / tests: teams of `width` sweep workgroups (alpine_info.team_width_*): 0 = the library's own choice, 1 = none.  Same
  * results up to summation order. */
