@@ -35,9 +35,10 @@ struct CellView {
 struct alpine_ctx {
     // geometry
     int G = 0, N = 0, K = 0, KP = 0, KT = 0, n_cov = 0;
-    // wide model (128 < K <= 256, kernels_wide.hpp): KP = 256, KT = 4 = tiles per HALF, factors in the blocked layout [2][rows][128]
+    // wide model (128 < K <= 1024, kernels_wide.hpp): NH = ceil(K / 128) halves, KP = 128 NH, KT = 4 = tiles per HALF, factors in the blocked layout [NH][rows][128]
     bool wide = false;
-    float *wide_den = nullptr, *wide_num = nullptr;     // [2][wide_den_rows][128] product A.M of the updates; [2][Np][128] transform numerator
+    int NH = 1;
+    float *wide_den = nullptr, *wide_num = nullptr;     // [NH][wide_den_rows][128] product A.M of the updates; [NH][Np][128] transform numerator
     bool wide_one_pass = false;                         // x3 sweeps of a wide model: stream_gemm_x3w2_kernel (X read once per sweep) instead of one x3w launch per component half
     u32x4* wide_panel3 = nullptr;                       // x3: the panel of the sweep about to run as three exact bf16 planes, k-packed [3][rows / 8][256][8] (stream_gemm_x3w2_kernel)
     int64_t wide_den_rows = 0;
@@ -320,7 +321,7 @@ static int geometry(const alpine_config* cfg, Geometry* g, std::string* why)
         nB += C * k;
         nY += C;
     }
-    if (K > 256) { *why = "total components > 256 not supported by this build"; return -1; }
+    if (K > WIDE_MAX_NH * WIDE_KH) { *why = "total components > 1024 not supported by this build"; return -1; }
     if (K > 128) {
         int guided = 0;
         for (int i = 0; i < cfg->n_covariates; ++i) guided += cfg->cov_components[i];
@@ -331,7 +332,7 @@ static int geometry(const alpine_config* cfg, Geometry* g, std::string* why)
     if (!(cfg->eps >= 0) || !(cfg->alpha_W >= 0) || !(cfg->orth_W >= 0) || !(cfg->l1_ratio_W >= 0 && cfg->l1_ratio_W <= 1)) { *why = "eps/alpha_W/orth_W must be >= 0 and l1_ratio_W in [0,1]"; return -1; }
     g->K = K;
     g->KT = K > 128 ? WIDE_KT : (K + 31) / 32;          // wide: tiles per half
-    g->KP = K > 128 ? 2 * WIDE_KH : 32 * g->KT;
+    g->KP = K > 128 ? (int)round_up(K, WIDE_KH) : 32 * g->KT;         // wide: NH = KP / 128 halves
     g->nstat = nstat; g->nB = nB; g->nYrows = nY;
     g->Gp = round_up(cfg->n_genes, 128);
     g->Np = round_up(cfg->n_cells, 128);
@@ -410,6 +411,7 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     c->G = (int)cfg->n_genes; c->N = (int)cfg->n_cells;
     c->K = g.K; c->KP = g.KP; c->KT = g.KT; c->Gp = g.Gp; c->Np = g.Np;
     c->wide = g.K > 128;
+    c->NH = c->wide ? g.KP / WIDE_KH : 1;
     c->n_cov = cfg->n_covariates;
     c->nstat = g.nstat; c->nB = g.nB; c->nYrows = g.nYrows;
     c->orth = cfg->orth_W; c->alpha = cfg->alpha_W; c->l1r = cfg->l1_ratio_W; c->eps = cfg->eps;
@@ -519,12 +521,12 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
                 }
             }
         }
-        *capA = std::max(*capA, ta * KP); *capB = std::max(*capB, tb * KP);
+        *capA = std::max(*capA, ta * KP); *capB = std::max(*capB, tb * KP);          // (wide: NH buffers of [.][128], cap / NH each)
     };
     // (wide models on the x3 sweeps: the one-pass kernel stream_gemm_x3w2_kernel, a wave owns 64 columns x all 256 components -- up to
     // 224 components: with all 16 component tiles its 256 accumulators + X ring + planes no longer fit the register file (68 - 248 B of
     // scratch per lane in the hot loop: 41 - 70 it/s at K = 256 against 69 on two passes), so K > 224 stays on the two-pass form)
-    c->wide_one_pass = c->wide && c->x3 && !c->x3_ablate && c->K <= 224;
+    c->wide_one_pass = c->wide && c->x3 && !c->x3_ablate && c->K <= 224;        // (K > 256: one launch per half)
     const int bf_default = c->x3 ? (c->wide_one_pass ? 256 : (c->KT <= 2 ? 1024 : 512)) : c->sweep_waves * SG_WAVE_F;
     piece_floats(bf_default, &c->piecesA_cap, &c->piecesB_cap);
     if (c->wide && c->x3 && !c->x3_ablate) piece_floats(c->wide_one_pass ? 512 : 256, &c->piecesA_cap, &c->piecesB_cap);    // (alpine_debug_set_option "wide_one_pass")
@@ -590,8 +592,9 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     {
         // fused tail: one partial H H^T block and one statistics row per 128-cell block of the H update (N x 2 KP bytes)
         c->tail_blocks = (int)((c->N + HS_CELLS - 1) / HS_CELLS);
-        ALLOC(c, c->gramPartH, float, (int64_t)c->tail_blocks * KP * KP);
-        ALLOC(c, c->statPartH, float, (int64_t)c->tail_blocks * std::max(1, c->nstat));
+        // (the blocked path of wide models has no fused tail: 4 MB per 128 cells at K = 1024 would be the largest allocation of the ctx)
+        ALLOC(c, c->gramPartH, float, c->wide ? 4 : (int64_t)c->tail_blocks * KP * KP);
+        ALLOC(c, c->statPartH, float, c->wide ? 4 : (int64_t)c->tail_blocks * std::max(1, c->nstat));
     }
     ALLOC(c, c->kind, int, kind.size());
     HOSTCOPY(c, c->kind, kind.data(), sizeof(int) * kind.size(), hipMemcpyHostToDevice);
@@ -923,7 +926,7 @@ extern "C" int alpine_set_factors(alpine_ctx* c, const float* W, const float* H,
     HIPCHK(c, hipSetDevice(c->device));
     const int K = c->K, KP = c->KP;
     // W: G x K -> [Gp][KP]   (wide: column half h -> [h][Gp][128])
-    const int halves = c->wide ? 2 : 1, kph = c->wide ? WIDE_KH : KP;
+    const int halves = c->wide ? c->NH : 1, kph = c->wide ? WIDE_KH : KP;
     HIPCHK(c, hipMemsetAsync(c->W, 0, sizeof(float) * c->Gp * KP, c->stream));
     HOSTCOPY(c, c->stage, W, sizeof(float) * (size_t)c->G * K, hipMemcpyHostToDevice);
     for (int h = 0; h < halves; ++h) {
@@ -962,7 +965,7 @@ extern "C" int alpine_get_factors(alpine_ctx* c, float* W, float* H, int64_t ldH
     if ((H && ldH < c->N)) return fail(c, ALPINE_ERR_BAD_ARG, "ldH too small");
     HIPCHK(c, hipSetDevice(c->device));
     const int K = c->K, KP = c->KP;
-    const int halves = c->wide ? 2 : 1, kph = c->wide ? WIDE_KH : KP;
+    const int halves = c->wide ? c->NH : 1, kph = c->wide ? WIDE_KH : KP;
     if (W) {
         for (int h = 0; h < halves; ++h) {
             const int kh = std::min(kph, K - h * kph);
@@ -1066,7 +1069,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
     // the division about to be launched must fit the pieces buffer it writes (sized in create_impl for every division this ctx
     // may use): an error here instead of an out-of-bounds write on the device
     const int64_t need = (int64_t)g.nwg * g.maxp * g.bf * (c->wide ? WIDE_KH : c->KP);        // (wide: one pass = one half of the buffer)
-    if (need > (which == 0 ? c->piecesA_cap : c->piecesB_cap) / (c->wide ? 2 : 1) || (which == 0 && c->transform_only))
+    if (need > (which == 0 ? c->piecesA_cap : c->piecesB_cap) / (c->wide ? c->NH : 1) || (which == 0 && c->transform_only))
         return fail(c, ALPINE_ERR_STATE, "internal: sweep %d needs %lld floats of pieces, the buffer holds %lld", which, (long long)need,
                     (long long)(which == 0 ? c->piecesA_cap : c->piecesB_cap));
     if (c->bf16) return launch_sweep_bf16(c, which, g);
@@ -1454,31 +1457,32 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
 
 // ---------------------------------------------------------------------------------- wide models (128 < K <= 256, kernels_wide.hpp)
 static float* wide_half(float* base, int64_t rows_pad, int h) { return base + (int64_t)h * rows_pad * WIDE_KH; }
-static float* wide_block(float* base, int a, int b) { return base + (int64_t)(a * 2 + b) * WIDE_KH * WIDE_KH; }
-// 16-component tiles of half h that hold real components (0 = all of them)
-static int wide_active16(const alpine_ctx* c, int h) { return h == 0 ? 0 : (c->K - WIDE_KH + 15) / 16; }
+static float* wide_block(const alpine_ctx* c, float* base, int a, int b) { return base + (int64_t)(a * c->NH + b) * WIDE_KH * WIDE_KH; }
+// 16-component tiles of half h that hold real components (0 = all of them): only the last half is partly filled
+static int wide_active16(const alpine_ctx* c, int h) { return h < c->NH - 1 ? 0 : ((c->K - (c->NH - 1) * WIDE_KH + 15) / 16) % 8; }
 
-// out (blocked [2][2][128][128]) = A^T A for a blocked A [2][R][128]
+// out (blocked [NH][NH][128][128]) = A^T A for a blocked A [NH][R][128]
 static int launch_gram_wide(alpine_ctx* c, float* A, int64_t R, float* out)
 {
     const int rpw = gram_rows_per_wave(R, c->n_cu);
     const int blocks = (int)((R + 4 * rpw - 1) / (4 * rpw));
     if (blocks > c->gramPart_cap) return fail(c, ALPINE_ERR_STATE, "internal: Gram partial buffer too small");
     const int n = WIDE_KH * WIDE_KH;
-    const int tiles[2] = {WIDE_KT, (c->K - WIDE_KH + 31) / 32};           // 32-component tiles with real components, per half
-    for (int a = 0; a < 2; ++a)
-        for (int b = a; b < 2; ++b) {
-            if (tiles[a] == WIDE_KT && tiles[b] == WIDE_KT)
-                hipLaunchKernelGGL((gram_cross_kernel<WIDE_KT, true>), dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw,
-                                   WIDE_KT, WIDE_KT);
-            else
-                hipLaunchKernelGGL((gram_cross_kernel<WIDE_KT, false>), dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw,
-                                   tiles[a], tiles[b]);
-            hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, wide_block(out, a, b), n, blocks);
+    const int NH = c->NH;
+    int tiles[WIDE_MAX_NH];                                               // 32-component tiles with real components, per half
+    for (int h = 0; h < NH; ++h) tiles[h] = h < NH - 1 ? WIDE_KT : (c->K - (NH - 1) * WIDE_KH + 31) / 32;
+    for (int a = 0; a < NH; ++a)
+        for (int b = a; b < NH; ++b) {
+#define GRAM_X(TA_, TB_) hipLaunchKernelGGL((gram_cross_kernel<WIDE_KT, TA_, TB_>), dim3(blocks), dim3(256), 0, c->stream, wide_half(A, R, a), wide_half(A, R, b), c->gramPart, (int)R, rpw)
+            // (a <= b and only the last half is partly filled: the tile counts are (4, 4), (4, t) or (t, t))
+            if (tiles[a] == WIDE_KT) { switch (tiles[b]) { case 1: GRAM_X(4, 1); break; case 2: GRAM_X(4, 2); break; case 3: GRAM_X(4, 3); break; default: GRAM_X(4, 4); break; } }
+            else { switch (tiles[b]) { case 1: GRAM_X(1, 1); break; case 2: GRAM_X(2, 2); break; default: GRAM_X(3, 3); break; } }
+#undef GRAM_X
+            hipLaunchKernelGGL(reduce_many_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, c->gramPart, wide_block(c, out, a, b), n, blocks);
+            // block (b, a) = block (a, b) transposed (the same products summed in the same order)
+            if (b > a) hipLaunchKernelGGL(transpose_kernel, dim3(WIDE_KH / 32, WIDE_KH / 32), dim3(256), 0, c->stream, wide_block(c, out, a, b), (int64_t)WIDE_KH,
+                                          wide_block(c, out, b, a), (int64_t)WIDE_KH, WIDE_KH, WIDE_KH);
         }
-    // block (1, 0) = block (0, 1) transposed (the same products summed in the same order)
-    hipLaunchKernelGGL(transpose_kernel, dim3(WIDE_KH / 32, WIDE_KH / 32), dim3(256), 0, c->stream, wide_block(out, 0, 1), (int64_t)WIDE_KH, wide_block(out, 1, 0),
-                       (int64_t)WIDE_KH, WIDE_KH, WIDE_KH);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1488,7 +1492,7 @@ static int launch_wide_den(alpine_ctx* c, const float* A, int64_t rows_pad, cons
     WideDenArgs a{};
     a.rows_pad = (int)rows_pad; a.K = c->K; a.mode = mode;
     a.orth = (float)c->orth; a.l2 = (float)((1.0 - c->l1r) * c->alpha);
-    a.k_lo = k_lo; a.k_hi = k_hi; a.block_orth = block_orth ? 1 : 0;
+    a.k_lo = k_lo; a.k_hi = k_hi; a.block_orth = block_orth ? 1 : 0; a.nh = c->NH;
     if (rows_pad > c->wide_den_rows) return fail(c, ALPINE_ERR_STATE, "internal: the blocked update has %lld rows, its buffer holds %lld", (long long)rows_pad, (long long)c->wide_den_rows);
     const size_t lds = sizeof(float) * (WIDE_KH * WIDE_KH + 4 * 32 * (WIDE_KH + 4));
     if (lds > c->lds_dev) return fail(c, ALPINE_ERR_UNSUPPORTED, "internal: the blocked update needs %zu bytes of LDS, the device has %zu", lds, c->lds_dev);
@@ -1497,8 +1501,8 @@ static int launch_wide_den(alpine_ctx* c, const float* A, int64_t rows_pad, cons
     return 0;
 }
 
-// The sweep of a wide model over all 256 components: pieces of component half h land in pieces + h * cap / 2 (both [.][128] with the
-// geometry g).  x3: ONE launch of stream_gemm_x3w2_kernel (X read once); float32 MFMA: one launch per half of the blocked panel P.
+// The sweep of a wide model over all its components: pieces of component half h land in pieces + h * cap / NH (each [.][128] with the
+// geometry g).  x3 at K <= 224: ONE launch of stream_gemm_x3w2_kernel (X read once); else one launch per half of the blocked panel P.
 static int launch_sweeps_wide(alpine_ctx* c, const SweepGeom& g, const float* S, float* P, int64_t rows_pad, float* pieces, int64_t cap, int which)
 {
     int rc;
@@ -1508,6 +1512,7 @@ static int launch_sweeps_wide(alpine_ctx* c, const SweepGeom& g, const float* S,
         if (need > cap / 2 || (which == 0 && c->transform_only))
             return fail(c, ALPINE_ERR_STATE, "internal: sweep %d needs %lld floats of pieces per half, the buffer holds %lld", which, (long long)need, (long long)(cap / 2));
         if (g.bf != 256 * g.gw) return fail(c, ALPINE_ERR_STATE, "internal: the one-pass wide sweep needs 256-column workgroup tiles");
+        if (c->NH != 2) return fail(c, ALPINE_ERR_STATE, "internal: the one-pass wide sweep covers two component halves, the model has %d", c->NH);
         int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
         const int64_t ldS = g.F;
         const int m16 = (c->K + 15) / 16;                     // 9..16 tiles with real components; instantiated for the even counts
@@ -1531,9 +1536,9 @@ static int launch_sweeps_wide(alpine_ctx* c, const SweepGeom& g, const float* S,
         HIPCHK(c, hipGetLastError());
         return prof_end(c, evt);
     }
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < c->NH; ++h) {
         if ((rc = prof_begin(c, evt))) return rc;
-        if ((rc = launch_sweep(c, g, S, wide_half(P, rows_pad, h), pieces + h * (cap / 2), which, wide_active16(c, h)))) return rc;
+        if ((rc = launch_sweep(c, g, S, wide_half(P, rows_pad, h), pieces + h * (cap / c->NH), which, wide_active16(c, h)))) return rc;
         if ((rc = prof_end(c, evt))) return rc;
     }
     return 0;
@@ -1556,8 +1561,8 @@ static int phase1_wide(alpine_ctx* c, const CellView& v)
     HIPCHK(c, hipGetLastError());
     if ((rc = launch_gram_wide(c, v.H, v.Np, c->red + c->red_hht))) return rc;
     if ((rc = launch_sweeps_wide(c, v.gA, v.Xng, v.H, v.Np, c->piecesA, c->piecesA_cap, 0))) return rc;
-    for (int h = 0; h < 2; ++h)
-        if ((rc = launch_reduce_pieces(c, c->piecesA + h * (c->piecesA_cap / 2), wide_half(c->red, c->Gp, h), (int)c->Gp, v.gA, WIDE_KH))) return rc;
+    for (int h = 0; h < c->NH; ++h)
+        if ((rc = launch_reduce_pieces(c, c->piecesA + h * (c->piecesA_cap / c->NH), wide_half(c->red, c->Gp, h), (int)c->Gp, v.gA, WIDE_KH))) return rc;
     return 0;
 }
 
@@ -1565,13 +1570,12 @@ static int phase1_wide(alpine_ctx* c, const CellView& v)
 static int wide_h_apply(alpine_ctx* c, const CellView& v, const float* num_in, int k_lo, int k_hi, int only_cov)
 {
     const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)v.N + 3) / 4);
-    const float* p0 = c->piecesB;
-    const float* p1 = c->piecesB + c->piecesB_cap / 2;
+    const int64_t pstride = c->piecesB_cap / c->NH;
     if (c->loss_type == ALPINE_LOSS_KL)
-        hipLaunchKernelGGL(wide_h_apply_kernel<0>, dim3(blocks), dim3(256), 0, c->stream, v.H, c->wide_den, p0, p1, v.gB, num_in, v.Y, c->B[c->bcur], c->meta,
+        hipLaunchKernelGGL(wide_h_apply_kernel<0>, dim3(blocks), dim3(256), 0, c->stream, v.H, c->wide_den, c->piecesB, pstride, c->NH, v.gB, num_in, v.Y, c->B[c->bcur], c->meta,
                            v.N, v.Np, c->K, (float)c->eps, k_lo, k_hi, only_cov);
     else
-        hipLaunchKernelGGL(wide_h_apply_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, v.H, c->wide_den, p0, p1, v.gB, num_in, v.Y, c->B[c->bcur], c->meta,
+        hipLaunchKernelGGL(wide_h_apply_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, v.H, c->wide_den, c->piecesB, pstride, c->NH, v.gB, num_in, v.Y, c->B[c->bcur], c->meta,
                            v.N, v.Np, c->K, (float)c->eps, k_lo, k_hi, only_cov);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1584,7 +1588,7 @@ static int wide_w_step(alpine_ctx* c, bool update, int k_lo, int k_hi, bool bloc
     const float l1 = (float)(c->l1r * c->alpha);
     if (update && (rc = launch_wide_den(c, c->W, c->Gp, c->red + c->red_hht, 0, k_lo, k_hi, block_orth))) return rc;
     hipLaunchKernelGGL(wide_w_apply_kernel, dim3(c->ndot), dim3(256), 0, c->stream, c->W, c->red, c->wide_den, c->dotpart, c->G, c->Gp, c->K, l1,
-                       (float)c->eps, update ? 1 : 0, k_lo, k_hi);
+                       (float)c->eps, update ? 1 : 0, k_lo, k_hi, c->NH);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1622,7 +1626,7 @@ static int wide_loss_and_b(alpine_ctx* c, bool update, bool finalize)
     }
     if (update && c->n_cov > 0) {
         hipLaunchKernelGGL(b_update_kernel, dim3(1), dim3(256), 0, c->stream, c->B[c->bcur], c->B[c->bcur ^ 1], c->red + c->red_stats,
-                           wide_block(HHt, 0, 0), c->meta, WIDE_KH, (float)c->eps);                                    // guided components: block (0, 0)
+                           wide_block(c, HHt, 0, 0), c->meta, WIDE_KH, (float)c->eps);                                    // guided components: block (0, 0)
         HIPCHK(c, hipGetLastError());
         c->bcur ^= 1;
     }
@@ -1652,7 +1656,7 @@ static int transform_wide(alpine_ctx* c, int n_iter)
     if ((rc = launch_gram_wide(c, c->W, c->Gp, c->WtW))) return rc;
     if ((rc = launch_sweeps_wide(c, c->geomB, c->Xgn, c->W, c->Gp, c->piecesB, c->piecesB_cap, 1))) return rc;
     const int blocks = (int)std::min<int64_t>((int64_t)c->n_cu * 16, ((int64_t)c->N + 3) / 4);
-    hipLaunchKernelGGL(wide_num_kernel, dim3(blocks), dim3(256), 0, c->stream, c->wide_num, c->piecesB, c->piecesB + c->piecesB_cap / 2, c->geomB, c->N, c->Np);
+    hipLaunchKernelGGL(wide_num_kernel, dim3(blocks), dim3(256), 0, c->stream, c->wide_num, c->piecesB, c->piecesB_cap / c->NH, c->NH, c->geomB, c->N, c->Np);
     HIPCHK(c, hipGetLastError());
     for (int it = 0; it < n_iter; ++it) {
         if ((rc = launch_wide_den(c, c->H, c->Np, c->WtW, 1, 0, c->K, false))) return rc;
@@ -1899,7 +1903,7 @@ extern "C" int alpine_batch_begin(alpine_ctx* c, const int64_t* idx, int64_t n)
     // gather the view: rows of the cells x genes copy, rows of H, columns of Y; then the genes x cells copy by transpose
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, c->Xng, c->Gp, c->idx_dev, (int)n, (int)Bp, c->Xb_ng, c->Gp, (int)c->Gp);
     if (c->wide) {
-        for (int h = 0; h < 2; ++h)      // blocked factors: each half is a [rows][128] array of its own (the view's halves are Bp rows apart)
+        for (int h = 0; h < c->NH; ++h)  // blocked factors: each half is a [rows][128] array of its own (the view's halves are Bp rows apart)
             hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, c->stream, wide_half(c->H, c->Np, h), (int64_t)WIDE_KH, c->idx_dev, (int)n, (int)Bp,
                                wide_half(c->Hb, Bp, h), (int64_t)WIDE_KH, WIDE_KH);
     } else {
@@ -1958,7 +1962,7 @@ extern "C" int alpine_batch_end(alpine_ctx* c)
     if ((rc = c->wide ? phase2_wide(c, c->batch_view, true, false) : phase2(c, c->batch_view, true, false))) return rc;
     const int nb = c->n_cu * 8;
     if (c->wide) {
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < c->NH; ++h)
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb), dim3(256), 0, c->stream, wide_half(c->Hb, c->batch_view.Np, h), (int64_t)WIDE_KH, c->idx_dev,
                                (int)c->batch_n, wide_half(c->H, c->Np, h), (int64_t)WIDE_KH, WIDE_KH);
     } else {
@@ -2083,7 +2087,7 @@ extern "C" int alpine_scale(alpine_ctx* c)
     if (rc) return rc;
     const int rows_per_block = 256;
     const int nblk = (c->G + rows_per_block - 1) / rows_per_block;
-    const int halves = c->wide ? 2 : 1, KP = c->wide ? WIDE_KH : c->KP;          // (wide: one half of the blocked factors at a time)
+    const int halves = c->wide ? c->NH : 1, KP = c->wide ? WIDE_KH : c->KP;      // (wide: one half of the blocked factors at a time)
     if ((int64_t)nblk * KP > c->f64part_n) return fail(c, ALPINE_ERR_UNSUPPORTED, "too many genes for the scaling scratch");
     for (int h = 0; h < halves; ++h) {
         const int K = std::min(KP, c->K - h * KP);
@@ -2126,8 +2130,8 @@ extern "C" int alpine_eval_recon_direct(alpine_ctx* c, double* out)
     while ((int64_t)gx * ((Bn + cells_per_block - 1) / cells_per_block) > c->f64part_n) cells_per_block *= 2;
     const int gy = (Bn + cells_per_block - 1) / cells_per_block;
     if (c->wide) {
-        if (swap) hipLaunchKernelGGL(eval_recon_wide_kernel, dim3(gx, gy), dim3(256), 0, c->stream, c->Xgn, c->Np, c->H, c->Np, c->W, c->Gp, A, Bn, cells_per_block, c->f64part);
-        else hipLaunchKernelGGL(eval_recon_wide_kernel, dim3(gx, gy), dim3(256), 0, c->stream, c->Xng, c->Gp, c->W, c->Gp, c->H, c->Np, A, Bn, cells_per_block, c->f64part);
+        if (swap) hipLaunchKernelGGL(eval_recon_wide_kernel, dim3(gx, gy), dim3(256), 0, c->stream, c->Xgn, c->Np, c->H, c->Np, c->W, c->Gp, A, Bn, cells_per_block, c->f64part, c->NH);
+        else hipLaunchKernelGGL(eval_recon_wide_kernel, dim3(gx, gy), dim3(256), 0, c->stream, c->Xng, c->Gp, c->W, c->Gp, c->H, c->Np, A, Bn, cells_per_block, c->f64part, c->NH);
         HIPCHK(c, hipGetLastError());
         return sum_f64_partials(c, gx * gy, out);
     }

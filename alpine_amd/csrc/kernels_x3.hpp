@@ -884,6 +884,9 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
         };
         // all but the `younger` youngest vector-memory operations of this wave have completed (the panel DMAs are older than an X reload issued after them)
         auto dma_wait = [&](bool x_reload_after) {
+#if defined(X3W2_ABLATE) && (X3W2_ABLATE & 1)
+            return;            // (tools/x3w2_bench.hip, timing only, wrong results: is the sweep waiting for its panel?)
+#endif
             if (x_reload_after) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
@@ -948,7 +951,11 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+#if defined(X3W2_ABLATE) && (X3W2_ABLATE & 4)
+            if (more && t == 0) dma_stage(t + 1, P_ ^ 1);      // (timing only, wrong results: no panel traffic after the first stages)
+#else
             if (more) dma_stage(t + 1, P_ ^ 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (t + 2 < nst) {
                 const float* src = xbase + (int64_t)(t + 2) * x_stage;
@@ -995,12 +1002,17 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
         using Slot0 = std::integral_constant<int, 0>;
         using Slot1 = std::integral_constant<int, 1>;
 
+#if defined(X3W2_ABLATE) && (X3W2_ABLATE & 2)
+#define X3W2_STAGE_BARRIER() do { } while (0)      // (timing only, wrong results: what do the per-stage barriers cost?)
+#else
+#define X3W2_STAGE_BARRIER() __syncthreads()
+#endif
         int t = 0;
         for (; t + 1 < nst; t += 2) {
             stage(Slot0{}, t);
-            __syncthreads();
+            X3W2_STAGE_BARRIER();
             stage(Slot1{}, t + 1);
-            __syncthreads();
+            X3W2_STAGE_BARRIER();
         }
         if (t < nst) { stage(Slot0{}, t); __syncthreads(); }
 

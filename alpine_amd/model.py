@@ -344,8 +344,8 @@ class ALPINE:
 
     # limits of libalpine_hip.so that the reference does not have ("Deviations"): checked here so that the
     # user gets a Python-side message before any device work, instead of a late native status
-    MAX_TOTAL_COMPONENTS = 256
-    MAX_FAST_COMPONENTS = 128              # up to here: the fused MFMA path; above: the blocked two-half path (float32 storage)
+    MAX_TOTAL_COMPONENTS = 1024
+    MAX_FAST_COMPONENTS = 128              # up to here: the fused MFMA path; above: the blocked path, ceil(K / 128) column blocks (float32 storage)
     MAX_COVARIATE_COMPONENTS = 64           # per covariate; their sum may reach the total
     MAX_COVARIATES = 16
 
@@ -360,7 +360,7 @@ class ALPINE:
             raise NotImplementedError(f"n_components + sum(n_covariate_components) = {self.total_components} > "
                                       f"{self.MAX_TOTAL_COMPONENTS} is not supported by the MI355X build")
         if self.total_components > self.MAX_FAST_COMPONENTS:
-            # 128 < K <= 256 runs on the blocked two-half path (kernels_wide.hpp)
+            # 128 < K <= 1024 runs on the blocked path (kernels_wide.hpp)
             if sum(ks) > self.MAX_FAST_COMPONENTS:
                 raise NotImplementedError(f"with more than {self.MAX_FAST_COMPONENTS} components in total, sum(n_covariate_components) must be <= "
                                           f"{self.MAX_FAST_COMPONENTS} in the MI355X build (got {sum(ks)})")

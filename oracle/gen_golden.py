@@ -219,6 +219,20 @@ CASES = [
     dict(name="als_mb_wide_k140", n_cells=140, n_genes=80, seed=42, T=4, fit_kwargs=dict(batch_size=64),
          covariates=[("c1", ["x", "y"], 0.0)],
          params=dict(n_components=132, n_covariate_components=[8], lam=[1e2], use_als=True, orth_W=0.02)),
+    # more than 256 components (round 4: the blocked path generalised to ceil(K / 128) <= 8 column blocks): an odd number of blocks with a
+    # partly filled last one, five blocks with 8 components in the last, the block-coordinate branch, mini-batches
+    dict(name="wide_k300", transform_iters=4, n_cells=130, n_genes=100, seed=50, T=5,
+         covariates=[("c1", ["x", "y", "z"], 0.05), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=290, n_covariate_components=[6, 4], lam=[1e3, 2e2], orth_W=0.05, alpha_W=0.3, l1_ratio_W=0.5)),
+    dict(name="wide_k520_fro", n_cells=110, n_genes=90, seed=51, T=4,
+         covariates=[("c1", ["x", "y"], 0.0)],
+         params=dict(n_components=510, n_covariate_components=[10], lam=[4.0], loss_type="frobenius")),
+    dict(name="als_wide_k270", n_cells=120, n_genes=96, seed=52, T=3,
+         covariates=[("c1", ["x", "y", "z"], 0.05), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=258, n_covariate_components=[7, 5], lam=[1e3, 2e2], use_als=True, orth_W=0.05, alpha_W=0.2, l1_ratio_W=0.5)),
+    dict(name="mb_wide_k300", n_cells=150, n_genes=90, seed=53, T=4, fit_kwargs=dict(batch_size=48),
+         covariates=[("c1", ["x", "y", "z"], 0.0), ("c2", ["p", "q"], 0.0)],
+         params=dict(n_components=291, n_covariate_components=[5, 4], lam=[1e3, 5e2], orth_W=0.05)),
     # degenerate inputs the reference accepts: genes that are zero in every cell, cells that are zero in every gene, a covariate
     # with ONE level, labels that are mostly missing, a matrix smaller than any tile
     dict(name="zeros_kl", transform_iters=5, n_cells=100, n_genes=70, seed=43, T=12, zero_genes=[0, 3, 40, 69], zero_cells=[0, 5, 77, 99],

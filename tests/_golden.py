@@ -15,11 +15,12 @@ SMALL_CASES = ["kl_1cov", "fro_1cov", "kl_reg", "kl_2cov_nan", "fro_2cov_reg", "
                "one_iter", "k74", "k105", "counts_2cov", "many_levels", "fro_3cov", "mid_counts", "nondefault",
                "k0_split", "k0_fro", "guided_wide", "guided_wide_fro",       # round 3: k_i = 0, more than 64 guided components
                "wide_k150", "wide_k200_fro",                                 # ... and more than 128 components in total
+               "wide_k300", "wide_k520_fro",                                 # round 4: more than 256 (3 and 5 column blocks of 128)
                "zeros_kl", "zeros_fro_reg", "one_level_sparse_labels", "tiny"]  # degenerate inputs: all-zero genes / cells, one-level covariate, 9 x 5 matrix
 BATCH_CASES = ["mb_random", "mb_weighted", "full_weighted", "weighted_skew",        # mini-batch / weighted sampling (stochastic)
-               "mb_wide_k150", "mb_weighted_wide_k140"]                            # ... with more than 128 components
+               "mb_wide_k150", "mb_weighted_wide_k140", "mb_wide_k300"]            # ... with more than 128 / 256 components
 ALS_CASES = ["als_kl", "als_fro_2cov", "als_k74_mb", "als_weighted_mb", "als_guided_wide",                  # use_als=True (block-coordinate branch)
-             "als_wide_k150", "als_wide_k160_fro", "als_mb_wide_k140", "tiny_als"]                                       # ... with more than 128 components
+             "als_wide_k150", "als_wide_k160_fro", "als_mb_wide_k140", "als_wide_k270", "tiny_als"]                                       # ... with more than 128 components
 ALL_CASES = SMALL_CASES + ["cfg1"]
 
 

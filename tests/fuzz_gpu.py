@@ -52,6 +52,8 @@ def make_case(seed):
         # wide models (128 < K <= 256: the blocked two-half path); guided components stay within the first 128 columns
         ks = [min(k, 40) for k in ks]
         Ku = int(np.random.default_rng(seed + 4243).integers(129 - min(sum(ks), 128), 257 - sum(ks)))
+        if seed >= 9000 and np.random.default_rng(seed + 4244).random() < 0.5:        # round 4 (own seed range): up to 1024 components
+            Ku = int(np.random.default_rng(seed + 4245).integers(257, 1025 - sum(ks)))
         G = min(G, 1500)
     loss = ["kl-divergence", "frobenius"][int(rng.integers(0, 2))]
     reg = bool(rng.integers(0, 2))

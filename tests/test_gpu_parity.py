@@ -71,10 +71,11 @@ def test_reduce_block_matches_numpy(name):
     XHt = blk[: info.genes_padded * KP].reshape(info.genes_padded, KP)
     HHt = blk[info.genes_padded * KP: info.genes_padded * KP + KP * KP].reshape(KP, KP)
     if K > 128:
-        # wide models keep their factors as two column halves (kernels_wide.hpp): XH^T is [2][Gp][128], H H^T four 128 x 128 blocks
-        XHt = np.concatenate(list(blk[: info.genes_padded * KP].reshape(2, info.genes_padded, 128)), axis=1)
-        b4 = blk[info.genes_padded * KP: info.genes_padded * KP + KP * KP].reshape(2, 2, 128, 128)
-        HHt = np.block([[b4[0, 0], b4[0, 1]], [b4[1, 0], b4[1, 1]]])
+        # wide models keep their factors as NH = KP / 128 column blocks (kernels_wide.hpp): XH^T is [NH][Gp][128], H H^T NH x NH blocks of 128 x 128
+        nh = KP // 128
+        XHt = np.concatenate(list(blk[: info.genes_padded * KP].reshape(nh, info.genes_padded, 128)), axis=1)
+        b4 = blk[info.genes_padded * KP: info.genes_padded * KP + KP * KP].reshape(nh, nh, 128, 128)
+        HHt = np.block([[b4[i, j] for j in range(nh)] for i in range(nh)])
     X64, H64 = c.X.T.astype(np.float64), c.H0.astype(np.float64)
     assert rel_fro(XHt[:G, :K], X64 @ H64.T) < 2e-6
     assert rel_fro(HHt[:K, :K], H64 @ H64.T) < 2e-6
@@ -313,14 +314,14 @@ def test_errors_are_loud():
         eng.run(1)                     # nothing uploaded yet
     eng.close()
     with pytest.raises(nat.AlpineNativeError):
-        nat.NativeShard(n_genes=64, n_cells=96, n_components=255, cov_components=[2], cov_levels=[2], lam=[1.0])       # K = 257 > 256
+        nat.NativeShard(n_genes=64, n_cells=96, n_components=1023, cov_components=[2], cov_levels=[2], lam=[1.0])      # K = 1025 > 1024
     with pytest.raises(nat.AlpineNativeError, match="need the float32 storage"):
         nat.NativeShard(n_genes=64, n_cells=96, n_components=200, cov_components=[2], cov_levels=[2], lam=[1.0], x_dtype="bf16")
     with pytest.raises(nat.AlpineNativeError, match="must fit in the first 128 columns"):
         nat.NativeShard(n_genes=64, n_cells=96, n_components=50, cov_components=[60, 50, 40], cov_levels=[2, 2, 2], lam=[1.0, 1.0, 1.0])
 
 
-TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74", "k0_split", "guided_wide", "wide_k150", "zeros_kl", "tiny"]
+TRANSFORM_CASES = ["kl_1cov", "kl_2cov_nan", "ragged", "k74", "k0_split", "guided_wide", "wide_k150", "wide_k300", "zeros_kl", "tiny"]
 
 
 @pytest.mark.parametrize("name", TRANSFORM_CASES)

@@ -82,10 +82,11 @@ def test_random_shape_als_and_minibatch_vs_oracle(seed):
     _als_and_minibatch_vs_oracle(seed)
 
 
-@pytest.mark.parametrize("seed,Ku", [(120, 129), (121, 140), (122, 200), (123, 250), (124, 131), (125, 170)])
+@pytest.mark.parametrize("seed,Ku", [(120, 129), (121, 140), (122, 200), (123, 250), (124, 131), (125, 170),
+                                     (126, 257), (127, 300), (128, 385), (129, 512), (130, 640)])          # round 4: 3, 4 and 5 column blocks
 def test_wide_als_and_minibatch_vs_oracle(seed, Ku):
-    """The same on the blocked two-half path (128 < K <= 256): gathered views of the blocked H, the group loop with block-local
-    orthogonality over both halves, epoch loss rows."""
+    """The same on the blocked path (128 < K <= 1024, ceil(K / 128) column blocks): gathered views of the blocked H, the group loop with
+    block-local orthogonality over all blocks, epoch loss rows."""
     _als_and_minibatch_vs_oracle(seed, Ku=Ku)
 
 
@@ -94,7 +95,7 @@ def _als_and_minibatch_vs_oracle(seed, Ku=None):
     p, X, Ys, _, _ = _case(seed)
     if Ku is not None:
         p.n_components = Ku - sum(p.n_covariate_components) if seed % 3 else Ku      # K = Ku exactly, or Ku unguided + the guided ones
-        p.n_components = min(p.n_components, 256 - sum(p.n_covariate_components))
+        p.n_components = min(p.n_components, 1024 - sum(p.n_covariate_components))
     if not p.n_covariate_components:            # the reference's ALS / sampler code needs at least one covariate
         p.n_covariate_components, p.lam = [2], [10.0]
         Ys = [np.eye(2, dtype=np.float32)[np.random.default_rng(seed).integers(0, 2, size=X.shape[0])]]
@@ -271,9 +272,14 @@ def test_fuzz_regressions(seed):
     (120, [60, 60], [2, 4], "frobenius", True),           # K = 240, the guided components fill 120 of the first half's 128 columns
     (256, [], [], "frobenius", False),                    # the largest model: both halves full
     (200, [0, 7], [2, 3], "kl-divergence", False),
+    (257, [], [], "kl-divergence", True),                 # round 4, more than 256: one component in the third block
+    (384, [], [], "frobenius", False),                    # three full blocks
+    (300, [60, 60], [2, 4], "kl-divergence", True),       # K = 420: four blocks, 36 components in the last, guided ones fill 120 of the first
+    (1024, [], [], "frobenius", False),                   # the largest model: eight full blocks
+    (700, [0, 7], [2, 3], "kl-divergence", False),        # six blocks, 67 components in the last
 ])
 def test_wide_models_vs_oracle(Ku, ks, levels, loss, reg):
-    """128 < K <= 256: the blocked two-half path (kernels_wide.hpp; every update as den = A.M on the MFMA + an elementwise apply, the
+    """128 < K <= 1024: the blocked path (kernels_wide.hpp; every update as den = A.M on the MFMA + an elementwise apply, the
     sweeps once per half) against the oracle's fused iteration, ragged G and N, x3 and f32 sweeps, loss rows included."""
     _fit_vs_oracle(300 + Ku, G=203, N=517, Ku=Ku, ks=ks, levels=levels, loss=loss, iters=3, reg=reg)
 

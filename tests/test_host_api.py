@@ -214,9 +214,9 @@ def test_build_limits_are_reported_from_python_before_any_device_work():
     a.obs["d"] = a.obs["c"].copy()
     with pytest.raises(NotImplementedError, match="for ONE covariate"):
         ALPINE(n_components=3, n_covariate_components=[65, 3], lam=[1.0, 1.0]).fit(a, covariate_keys=["c", "d"], max_iter=1)
-    with pytest.raises(NotImplementedError, match="> 256"):
-        ALPINE(n_components=255, n_covariate_components=[2], lam=[1.0]).fit(a, covariate_keys=["c"], max_iter=1)
-    # 128 < K <= 256: the blocked two-half path -- float32 storage, guided components in the first half
+    with pytest.raises(NotImplementedError, match="> 1024"):
+        ALPINE(n_components=1023, n_covariate_components=[2], lam=[1.0]).fit(a, covariate_keys=["c"], max_iter=1)
+    # 128 < K <= 1024: the blocked path -- float32 storage, guided components in the first 128 columns
     with pytest.raises(NotImplementedError, match="must be <= 128"):
         ALPINE(n_components=100, n_covariate_components=[64, 64, 10], lam=[1.0, 1.0, 1.0]).fit(a, covariate_keys=["c", "d", "c"], max_iter=1)
     with pytest.raises(NotImplementedError, match="need float32 storage"):
