@@ -60,6 +60,8 @@ WORKLOADS = {
     # cfg3's matrix with K = 140 + [5, 5] = 150 and K = 246 + [5, 5] = 256: the blocked two-half path for 128 < K <= 256 (kernels_wide.hpp)
     "cfg3_k150": dict(genes=20000, cells=200000, ku=140, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
     "cfg3_k256": dict(genes=20000, cells=200000, ku=246, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
+    "cfg3_k512": dict(genes=20000, cells=200000, ku=502, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),      # four column blocks of 128 (round 4)
+    "cfg3_k1024": dict(genes=20000, cells=200000, ku=1014, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),   # the largest model this build takes
 }
 
 
@@ -573,7 +575,7 @@ def main():
         launches = m["n_a"] + m["n_b"]
         avg_ms = (m["ms_a"] + m["ms_b"]) / max(1, launches)
         one_pass = K > 128 and dtype == "x3" and K <= 224           # the library's rule (alpine_create): stream_gemm_x3w2_kernel up to 224 components
-        passes = 2 if (K > 128 and not one_pass) else 1            # else each sweep of a wide model is two launches, one per component half
+        passes = -(-K // 128) if (K > 128 and not one_pass) else 1  # else each sweep of a wide model is one launch per column block of 128 components
         flops_per_launch = 2.0 * G * n_loc * K / passes           # algorithmic, unpadded K (4GNK per iteration / 2 sweeps)
         bytes_per_launch = (4.0 if dtype in ("f32", "x3") else 2.0) * G * n_loc   # X read once per sweep (counts: ONE bf16 plane in split mode)
         ach_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0

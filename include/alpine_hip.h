@@ -81,9 +81,9 @@ typedef struct {
     int32_t device_id;              /* HIP device ordinal */
     int64_t n_genes;                /* G */
     int64_t n_cells;                /* N held by THIS ctx (the local shard of the cell axis) */
-    int32_t n_components;           /* unguided K_u            (main.py:49).  K = K_u + sum k_i <= 256; K <= 128 is the fast path, 128 < K <= 256 a
-                                       blocked two-half path (slower: X is read once per half and sweep; float32 storage only, no bf16-plane
-                                       flags), guided components within the first 128 columns (sum k_i <= 128) */
+    int32_t n_components;           /* unguided K_u            (main.py:49).  K = K_u + sum k_i <= 1024; K <= 128 is the fast path, 128 < K <= 1024 a
+                                       blocked path of ceil(K / 128) column blocks (slower: above K = 224 X is read once per block and sweep; float32
+                                       storage only, no bf16-plane flags), guided components within the first 128 columns (sum k_i <= 128) */
     int32_t n_covariates;           /* C = len(covariate_keys) (main.py:50) */
     const int32_t* cov_components;  /* k_i, length C           (main.py:50); 0 <= k_i <= 64 (0: the covariate only contributes its loss column) */
     const int32_t* cov_levels;      /* C_i = rows of Y_i, length C (encoder.py:31) */

@@ -37,7 +37,9 @@ def make_case(seed):
     ks = [int(rng.integers(0, 7)) for _ in range(n_cov)]
     levels = [int(rng.choice([1, 2, 3, 5])) for _ in range(n_cov)]
     Ku = int(rng.choice([1, 2, 6, 20, 33, 64, 90])) if rng.random() < 0.85 else int(rng.integers(129, 200))
-    Ku = max(1, min(Ku, 256 - sum(ks)))
+    if 60000 <= seed < 70000 and np.random.default_rng(seed + 98).random() < 0.15:      # round 4 (own seed range, own generators): up to 1024 components in total
+        Ku = int(np.random.default_rng(seed + 99).integers(257, 1000))
+    Ku = max(1, min(Ku, 1024 - sum(ks)))
     loss = ["kl-divergence", "frobenius"][int(rng.integers(0, 2))]
     reg = rng.random() < 0.5
     kind = str(rng.choice(["gamma", "counts", "sparse"]))

@@ -61,7 +61,7 @@ def _check_against_golden(c, r, local):
     return H
 
 
-@pytest.mark.parametrize("case_name,local", [("kl_2cov_nan", False), ("counts_2cov", True), ("fro_2cov_reg", False), ("wide_k200_fro", False)])
+@pytest.mark.parametrize("case_name,local", [("kl_2cov_nan", False), ("counts_2cov", True), ("fro_2cov_reg", False), ("wide_k200_fro", False), ("wide_k520_fro", False)])
 def test_native_loop_two_ranks_full_batch(case_name, local, tmp_path):
     """alpine_run with a two-rank communicator: one exchange of the whole reduce block per iteration (+ one for the last
     loss row).  Equal to the single-device run up to the summation order of the two shards."""
@@ -83,7 +83,7 @@ def test_native_loop_two_ranks_block_coordinate(case_name, local, tmp_path):
     _check_against_golden(c, r, local)
 
 
-@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", True), ("weighted_skew", False), ("mb_wide_k150", True)])
+@pytest.mark.parametrize("case_name,local", [("mb_random", False), ("mb_weighted", True), ("weighted_skew", False), ("mb_wide_k150", True), ("mb_wide_k300", False)])
 def test_native_loop_two_ranks_minibatch(case_name, local, tmp_path):
     """Mini-batches: alpine_batch_step (gather, phase 1, exchange, phase 2, scatter) and alpine_epoch_loss with the
     communicator attached, including batches of which a rank holds no cell (weighted_skew: most draws fall into rank 0's

@@ -10,9 +10,9 @@ import fuzz_model_gpu as fm
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", list(range(40000, 40032)) + [40775, 40885, 40962])
+@pytest.mark.parametrize("seed", list(range(40000, 40032)) + [40775, 40885, 40962] + [60000, 60007, 60036, 60041, 60044, 60060])
 def test_random_api_call_vs_oracle(seed):
-    """40775: a degenerate fit (the reference's scaling divides by zero: NaN pattern must match); 40885 / 40962: the cases during which the
+    """60000 ...: more than 256 components in total (round 4: the blocked path with 3 - 8 column blocks).  40775: a degenerate fit (the reference's scaling divides by zero: NaN pattern must match); 40885 / 40962: the cases during which the
     round-3 campaign's process died of heap corruption (device-to-host copies landing in freed memory; fixed in alpine_hip.hip)."""
     fm.run_case(seed)
 

@@ -60,7 +60,7 @@ def _worker(rank, world, port, case_name, out_dir, local=False, shard_comm="auto
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "ragged", "wide_k150"])
+@pytest.mark.parametrize("case_name", ["kl_2cov_nan", "ragged", "wide_k150", "wide_k300"])
 def test_two_ranks_one_gpu(case_name, tmp_path):
     import torch.multiprocessing as mp
     from _golden import assert_loss_rows_close, load_case, rel_fro
@@ -131,7 +131,7 @@ def test_two_ranks_minibatch(case_name, local, tmp_path):
     assert_loss_rows_close(r[0]["losses"], c.loss_history, n_cells=c.X.shape[0])
 
 
-@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True), ("als_wide_k150", False)])
+@pytest.mark.parametrize("case_name,local", [("als_kl", False), ("als_fro_2cov", True), ("als_wide_k150", False), ("als_wide_k270", False)])
 def test_two_ranks_use_als(case_name, local, tmp_path):
     """Block-coordinate branch sharded over two ranks: one extra all-reduce of the K x K H H^T slot per component group."""
     import torch.multiprocessing as mp
