@@ -68,6 +68,24 @@ __device__ __forceinline__ void x3_split8_scalar(const float (&v)[8], u32x4 (&b)
     }
 }
 
+// A wave-uniform 64-bit address as a SCALAR register pair (the compiler's divergence analysis already knows most of these are uniform; the
+// readfirstlane pins it), and loads through it in the saddr form of global_load: uniform base + ONE 32-bit lane offset.  Per-lane 64-bit
+// addresses of 8 rows (and of up to 12 panel pieces), which the compiler hoists out of a stage loop as loop invariants, cost 16 - 40
+// vector registers in the kernels that have none to spare -- spilled, and re-loaded in the loop behind an s_waitcnt vmcnt(0).
+__device__ __forceinline__ unsigned long long x3_uniform_u64(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32)
+           | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+__device__ __forceinline__ f32x4 x3_load_nt_saddr(const char* uniform_row, unsigned lane_off)
+{
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef const __attribute__((address_space(1))) f32x4* gf32x4_p;
+    const unsigned long long urow = x3_uniform_u64(reinterpret_cast<unsigned long long>(uniform_row));
+    asm volatile("" : "+v"(lane_off));          // (opaque: keeps the compiler from folding the lane offset into a hoisted per-lane 64-bit base)
+    return __builtin_nontemporal_load(reinterpret_cast<gf32x4_p>(reinterpret_cast<gchar_p>(urow) + lane_off));
+}
+
 // One panel stage = X3_RING k-steps.  Per k-step: A fragments of all three panel planes (double-buffered over k-steps),
 // then per 128-column half: 4 x (split one tile's 8 x float32 into planes, 6*KT MFMAs), then the half's 8 loads are
 // re-issued for the same k-step of the next stage.
@@ -665,17 +683,8 @@ void stream_gemm_x3v_kernel(const float* __restrict__ S, const float* __restrict
         const char* xrow0 = reinterpret_cast<const char*>(S + (int64_t)r_begin * ldS + f0);
         const unsigned x_lane = (unsigned)((int64_t)(8 * kg) * ldS + 4 * c16) * 4u;          // < 2^32: 24 rows of at most 2^25 floats
         auto load_x = [&](int t, int cg) {
-            typedef const __attribute__((address_space(1))) char* gchar_p;
-            typedef const __attribute__((address_space(1))) f32x4* gf32x4_p;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned long long row = reinterpret_cast<unsigned long long>(xrow0 + (((int64_t)t * ROWS + e) * ldS + 64 * cg) * 4);
-                const unsigned long long urow = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(row >> 32)) << 32)
-                                                | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)row);      // (wave-uniform by construction: into scalar registers)
-                unsigned lane_off = x_lane;
-                asm volatile("" : "+v"(lane_off));          // (opaque: keeps the compiler from folding the lane offset into a hoisted per-lane 64-bit base)
-                x[e] = __builtin_nontemporal_load(reinterpret_cast<gf32x4_p>(reinterpret_cast<gchar_p>(urow) + lane_off));
-            }
+            for (int e = 0; e < 8; ++e) x[e] = x3_load_nt_saddr(xrow0 + (((int64_t)t * ROWS + e) * ldS + 64 * cg) * 4, x_lane);
         };
         const int lds_lane = (kg * KP + c16) * 8;
 
@@ -867,7 +876,10 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
         // pieces 4 i + w.  hipcc does not see these loads (inline assembly: M0 = the LDS address, saved and restored around the
         // instruction), so THIS code waits for them -- dma_wait before the barrier that publishes the buffer; they retire in order with the X
         // loads, whose waits the compiler still counts itself (a hidden older load only makes such a wait cover more, never less).
-        const u32x4* pbase = Pk + (int64_t)(r_begin / 8) * KP + lane;
+        // (source = a wave-uniform KiB of the packed panel in scalar registers + the lane's 16 bytes: the saddr form -- the per-lane 64-bit
+        // addresses of up to 12 pieces, hoisted out of the stage loop, were spilled at M16A >= 14 and re-loaded behind an s_waitcnt vmcnt(0))
+        const u32x4* pbase = Pk + (int64_t)(r_begin / 8) * KP;
+        const unsigned dma_lane = (unsigned)lane * 16u;
         auto dma_stage = [&](int t, int b) {
             const unsigned lbase = (unsigned)(size_t)(&lds[b][0]);
 #pragma unroll
@@ -875,11 +887,11 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
                 const int piece = 4 * i + wave;                     // wave-uniform
                 if (piece >= PIECES) break;
                 const int q = piece / M16A, kk = piece % M16A;      // plane, KiB within the plane's M16A KiB
-                const u32x4* src = pbase + q * plane_stride + (int64_t)t * STAGE_V4 + kk * 64;
+                const unsigned long long src = x3_uniform_u64(reinterpret_cast<unsigned long long>(pbase + q * plane_stride + (int64_t)t * STAGE_V4 + kk * 64));
                 const unsigned dst = lbase + (unsigned)(q * 2 * STAGE_BF16 + kk * 1024);
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(dma_lane), "s"(src), "s"(dst) : "memory");
             }
         };
         // all but the `younger` youngest vector-memory operations of this wave have completed (the panel DMAs are older than an X reload issued after them)
@@ -913,9 +925,10 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // this lane's float4 of row r_begin + 8 kg (+ e), columns f0 + 4 c16 .. + 3 (element t -> column tile t, column c16)
-        const float* xbase = S + (int64_t)(r_begin + 8 * kg) * ldS + f0 + 4 * c16;
-        const int64_t x_stage = (int64_t)ROWS * ldS;
+        // this lane's float4 of row r_begin + 8 kg (+ e), columns f0 + 4 c16 .. + 3 (element t -> column tile t, column c16): wave-uniform row
+        // address + one 32-bit lane offset (x3_load_nt_saddr)
+        const char* xrow0 = reinterpret_cast<const char*>(S + (int64_t)r_begin * ldS + f0);
+        const unsigned x_lane = (unsigned)((int64_t)(8 * kg) * ldS + 4 * c16) * 4u;          // < 2^32: 24 rows of at most 2^25 floats
         const int lds_lane = (kg * KP + c16) * 8;
 
         __builtin_amdgcn_sched_barrier(0);
@@ -923,7 +936,7 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int e = 0; e < 8; ++e)         // (a one-stage span re-reads stage 0 into the second slot: valid memory, never used)
-                x[p][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (int64_t)(p < nst ? p : 0) * x_stage + (int64_t)e * ldS));
+                x[p][e] = x3_load_nt_saddr(xrow0 + ((int64_t)(p < nst ? p : 0) * ROWS + e) * ldS * 4, x_lane);
         __builtin_amdgcn_sched_barrier(0);
         dma_wait(false);                 // (stage 0's panel; also drains the X prologue once per span)
         __syncthreads();
@@ -958,9 +971,8 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
 #endif
             __builtin_amdgcn_sched_barrier(0);
             if (t + 2 < nst) {
-                const float* src = xbase + (int64_t)(t + 2) * x_stage;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[P_][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (int64_t)e * ldS));
+                for (int e = 0; e < 8; ++e) x[P_][e] = x3_load_nt_saddr(xrow0 + ((int64_t)(t + 2) * ROWS + e) * ldS * 4, x_lane);
             }
             __builtin_amdgcn_sched_barrier(0);
             auto lda = [&](int m, u32x4 (&a)[3]) {

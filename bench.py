@@ -59,6 +59,7 @@ WORKLOADS = {
     "cfg3_k32": dict(genes=20000, cells=200000, ku=22, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
     # cfg3's matrix with K = 140 + [5, 5] = 150 and K = 246 + [5, 5] = 256: the blocked two-half path for 128 < K <= 256 (kernels_wide.hpp)
     "cfg3_k150": dict(genes=20000, cells=200000, ku=140, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
+    "cfg3_k216": dict(genes=20000, cells=200000, ku=206, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),      # 14 of 16 component tiles: the widest one-pass sweep
     "cfg3_k256": dict(genes=20000, cells=200000, ku=246, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),
     "cfg3_k512": dict(genes=20000, cells=200000, ku=502, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),      # four column blocks of 128 (round 4)
     "cfg3_k1024": dict(genes=20000, cells=200000, ku=1014, kcov=[5, 5], alpha_W=1.0, orth_W=0.1, l1_ratio_W=0.5),   # the largest model this build takes
