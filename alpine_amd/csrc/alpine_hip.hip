@@ -145,6 +145,7 @@ struct alpine_ctx {
     double x_multi_plane_frac = 0;    // fraction of the elements of X that are not exactly one bf16 plane
     int x3_two_wave_opt = -1;         // alpine_debug_set_option "x3_two_wave": -1 = the library's choice, 0 = never, 1 = wherever the kernel exists
     bool x3_two_wave = false;         // the K in (64, 128] sweeps run stream_gemm_x3v_kernel (two waves per SIMD; decided in alpine_finalize_X)
+    bool wide_two_wave = false;       // the one-pass sweep of a wide model runs its 8-wave form (one-plane data, K <= 160; decided in alpine_finalize_X)
     bool x_one_plane = false;         // ... and NONE is (census of alpine_finalize_X): the K > 64 sweeps then run the form without split and zero-plane test
     bool team_ok = true;              // teams pay for this ctx's data and model size (decided in alpine_finalize_X; see team_width)
     // profiling
@@ -668,7 +669,7 @@ extern "C" int alpine_get_info(alpine_ctx* c, alpine_info* info)
     info->x_sqnorm = c->xnorm2;
     info->x_multi_plane_fraction = c->x_multi_plane_frac;
     info->x3_wide = c->x3 && c->x3_wide ? 1 : 0;
-    info->sweep_waves_per_simd = !c->x3 ? 0 : (c->x3_two_wave ? 2 : 1);
+    info->sweep_waves_per_simd = !c->x3 ? 0 : ((c->x3_two_wave || c->wide_two_wave) ? 2 : 1);
     info->span_rows_a = c->geomA.L; info->span_rows_b = c->geomB.L;
     info->spans_per_workgroup_a = c->geomA.sub; info->spans_per_workgroup_b = c->geomB.sub;
     info->xcd_bias_per_mille = c->xcd_bias_pm; info->xcc_of_workgroup0 = c->xcc_of_wg0;
@@ -859,6 +860,11 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         c->x3_two_wave = c->x3 && !c->wide && c->KT >= 3 && !c->x3_ablate && c->x3_variant < 0 &&
                          (c->x3_two_wave_opt == 1 || (c->x3_two_wave_opt < 0 && !c->x_one_plane));
         if (c->x3_two_wave) c->x3_wide = true;
+        // 128 < K <= 160 on one-plane data: the 8-wave form of the one-pass sweep (two waves per SIMD, 512-column workgroup tiles)
+        {
+            const bool w2 = c->wide_one_pass && c->x_one_plane && c->x3_variant < 0 && c->K <= 160 && c->x3_two_wave_opt != 0;
+            if (w2 != c->wide_two_wave) { c->wide_two_wave = w2; apply_sweep_geometry(c, w2 ? 512 : 256); c->tail_valid = false; }
+        }
         const bool team_ok = c->KT >= 3 || c->x_multi_plane_frac <= 0.01;
         if (c->x3 && team_ok != c->team_ok) { c->team_ok = team_ok; apply_sweep_geometry(c, c->sweep_bf); c->tail_valid = false; }
         if (c->x3 && c->KT <= 2) {
@@ -1511,7 +1517,8 @@ static int launch_sweeps_wide(alpine_ctx* c, const SweepGeom& g, const float* S,
         const int64_t need = (int64_t)g.nwg * g.maxp * g.bf * WIDE_KH;
         if (need > cap / 2 || (which == 0 && c->transform_only))
             return fail(c, ALPINE_ERR_STATE, "internal: sweep %d needs %lld floats of pieces per half, the buffer holds %lld", which, (long long)need, (long long)(cap / 2));
-        if (g.bf != 256 * g.gw) return fail(c, ALPINE_ERR_STATE, "internal: the one-pass wide sweep needs 256-column workgroup tiles");
+        if (g.bf != (c->wide_two_wave ? 512 : 256) * g.gw)
+            return fail(c, ALPINE_ERR_STATE, "internal: the one-pass wide sweep was divided for %d-column workgroup tiles, its kernel works on %d", g.bf / std::max(1, g.gw), c->wide_two_wave ? 512 : 256);
         if (c->NH != 2) return fail(c, ALPINE_ERR_STATE, "internal: the one-pass wide sweep covers two component halves, the model has %d", c->NH);
         int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
         const int64_t ldS = g.F;
@@ -1531,7 +1538,9 @@ static int launch_sweeps_wide(alpine_ctx* c, const SweepGeom& g, const float* S,
                                                         pieces, pieces + cap / 2, ldS, g, xcc_out); \
                       else hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M_, false>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, c->wide_panel3, plane_stride, \
                                               pieces, pieces + cap / 2, ldS, g, xcc_out); } while (0)
-        if (m16 <= 10) X3W2(10); else if (m16 <= 12) X3W2(12); else if (m16 <= 14) X3W2(14); else X3W2(16);
+        if (c->wide_two_wave)
+            hipLaunchKernelGGL((stream_gemm_x3w2_kernel<10, true, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, S, c->wide_panel3, plane_stride, pieces, pieces + cap / 2, ldS, g, xcc_out);
+        else if (m16 <= 10) X3W2(10); else if (m16 <= 12) X3W2(12); else if (m16 <= 14) X3W2(14); else X3W2(16);
 #undef X3W2
         HIPCHK(c, hipGetLastError());
         return prof_end(c, evt);
@@ -2235,6 +2244,7 @@ extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int valu
     else if (n == "wide_one_pass") {
         if (!c->wide || !c->x3 || c->x3_ablate) return 0;     // only wide models on the x3 sweeps have the two forms
         c->wide_one_pass = value != 0;
+        c->wide_two_wave = false;                            // (alpine_finalize_X decides again)
         apply_sweep_geometry(c, c->wide_one_pass ? 256 : 512);
     }
     else if (n == "x3_narrow") {

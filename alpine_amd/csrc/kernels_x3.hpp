@@ -833,8 +833,11 @@ void pack_panel3_wide_kernel(const float* __restrict__ P0, const float* __restri
     }
 }
 
-template <int M16A, bool ONEPLANE = false>
-__global__ __launch_bounds__(256, 1)
+// NW = 8 (round 4, second half): TWO waves per SIMD -- 8 waves x 64 columns = 512-column workgroup tiles (half the panel bytes per byte of X), ONE
+// stage of X in flight per wave (re-issued right after the split), 256 registers per wave: 16 M16A accumulators + 32 + planes + fragments, which
+// fits for the one-plane form up to 10 component tiles (K <= 160).  Same pieces; the division is over 512-column tiles.
+template <int M16A, bool ONEPLANE = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1)
 void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restrict__ Pk, int64_t plane_stride,
                              float* __restrict__ pieces0, float* __restrict__ pieces1, int64_t ldS, SweepGeom g, int* __restrict__ xcc_out)
 {
@@ -842,14 +845,16 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
     static_assert(M16A >= 9 && M16A <= 16, "active 16-component tiles of a wide model");
     constexpr int KH = 128;
     constexpr int KP = 16 * M16A;                                     // panel components staged and multiplied (the pieces stay 2 x 128 wide)
-    constexpr int WAVE_F = 64, BLOCK_F = 4 * WAVE_F;
+    static_assert(NW == 4 || (NW == 8 && ONEPLANE && M16A <= 10), "two waves per SIMD: 256 registers per wave");
+    constexpr int WAVE_F = 64, BLOCK_F = NW * WAVE_F;
+    constexpr int RING = NW == 4 ? 2 : 1;                             // stages of X in flight per wave
     constexpr int ROWS = 32;                                          // rows per k-step = per panel stage
     static_assert(SG_ROW_ALIGN % ROWS == 0, "stream-K spans are whole stages");
     constexpr int STAGE_BF16 = ROWS * KP;                             // bf16 elements of one plane of a stage (16 KB)
     constexpr int STAGE_V4 = STAGE_BF16 / 8;                          // ... in 16-byte granules (64 per component tile = 1 KiB)
     constexpr int PIECES = 3 * M16A;                                  // 1-KiB pieces of a stage image [plane][M16A KiB]
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * STAGE_BF16];          // 6 KB per component tile and buffer: 96 KB at M16A = 16
-    __shared__ __attribute__((aligned(16))) float flush_tr[4][16 * (KH + 4)];              // 33 KB
+    __shared__ __attribute__((aligned(16))) float flush_tr[NW][16 * (KH + 4)];             // 33 KB (NW = 4)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -860,7 +865,7 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
     sg_team_of_block(g, blockIdx.x, team, member);
     sg_walk_init(walk, g, team);
 
-    f32x4 x[2][8];
+    f32x4 x[RING][8];
 
     int ft, r_begin, r_end;
     int64_t slot;
@@ -868,7 +873,7 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
         const int nst = (r_end - r_begin) / ROWS;
         const int wt = ft * g.gw + member;                 // this workgroup's BLOCK_F-wide tile (ft = the team's tile)
         if ((int64_t)wt * BLOCK_F >= g.F) continue;        // a member past the last column of a partly filled team tile (block-uniform)
-        const int f0 = (wt * 4 + wave) * WAVE_F;
+        const int f0 = (wt * NW + wave) * WAVE_F;
         const bool active = f0 < g.F;
 
         // Panel stage t -> LDS buffer b by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = one contiguous KiB of the LDS image per
@@ -883,8 +888,8 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
         auto dma_stage = [&](int t, int b) {
             const unsigned lbase = (unsigned)(size_t)(&lds[b][0]);
 #pragma unroll
-            for (int i = 0; i < (PIECES + 3) / 4; ++i) {
-                const int piece = 4 * i + wave;                     // wave-uniform
+            for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+                const int piece = NW * i + wave;                    // wave-uniform
                 if (piece >= PIECES) break;
                 const int q = piece / M16A, kk = piece % M16A;      // plane, KiB within the plane's M16A KiB
                 const unsigned long long src = x3_uniform_u64(reinterpret_cast<unsigned long long>(pbase + q * plane_stride + (int64_t)t * STAGE_V4 + kk * 64));
@@ -933,7 +938,7 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < RING; ++p)
 #pragma unroll
             for (int e = 0; e < 8; ++e)         // (a one-stage span re-reads stage 0 into the second slot: valid memory, never used)
                 x[p][e] = x3_load_nt_saddr(xrow0 + ((int64_t)(p < nst ? p : 0) * ROWS + e) * ldS * 4, x_lane);
@@ -953,7 +958,7 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
             for (int j = 0; j < 4; ++j) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = x[P_][e][j];
+                for (int e = 0; e < 8; ++e) v[e] = x[P_ % RING][e][j];
                 if constexpr (ONEPLANE) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) b[j][0][q] = x3_cvt2(v[2 * q], v[2 * q + 1]);       // exact: every value is one bf16 plane
@@ -970,17 +975,23 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
             if (more) dma_stage(t + 1, P_ ^ 1);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nst) {
+            if (t + RING < nst) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[P_][e] = x3_load_nt_saddr(xrow0 + ((int64_t)(t + 2) * ROWS + e) * ldS * 4, x_lane);
+                for (int e = 0; e < 8; ++e) x[P_ % RING][e] = x3_load_nt_saddr(xrow0 + ((int64_t)(t + RING) * ROWS + e) * ldS * 4, x_lane);
             }
             __builtin_amdgcn_sched_barrier(0);
             auto lda = [&](int m, u32x4 (&a)[3]) {
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp) a[pp] = *reinterpret_cast<const u32x4*>(lrow + pp * STAGE_BF16 + (16 * m) * 8);
             };
-            u32x4 a[2][3];
-            lda(0, a[0]);
+#ifdef X3W2_AHEAD
+            constexpr int AD = X3W2_AHEAD;                  // (tools/x3w2_bench.hip: A/B of the prefetch depth)
+#else
+            constexpr int AD = 1;                           // component tiles the fragment reads run ahead of the MFMAs
+#endif
+            u32x4 a[AD + 1][3];
+#pragma unroll
+            for (int m = 0; m < AD; ++m) lda(m, a[m]);
             // (an if-THEN per component tile, not two copies of the loop under an if / else: with the accumulators updated on two
             // different paths the register allocator no longer keeps each in ONE accumulator register across the join and shuttles them
             // through vector registers -- 1 040 v_accvgpr moves and 356 B of scratch per lane in that form, none in this one)
@@ -988,28 +999,28 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
 #pragma unroll
             for (int m = 0; m < M16A; ++m) {
                 asm volatile("" ::: "memory");              // (no motion of the fragment reads across component tiles before scheduling either)
-                if (m + 1 < M16A) lda(m + 1, a[(m + 1) & 1]);
+                if (m + AD < M16A) lda(m + AD, a[(m + AD) % (AD + 1)]);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m & 1][pp]), __builtin_bit_cast(bf16x8, b[j][0]), acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m % (AD + 1)][pp]), __builtin_bit_cast(bf16x8, b[j][0]), acc[m][j], 0, 0, 0);
                 if (full) {
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m & 1][pp]), __builtin_bit_cast(bf16x8, b[j][1]), acc[m][j], 0, 0, 0);
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m % (AD + 1)][pp]), __builtin_bit_cast(bf16x8, b[j][1]), acc[m][j], 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m & 1][0]), __builtin_bit_cast(bf16x8, b[j][2]), acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m % (AD + 1)][0]), __builtin_bit_cast(bf16x8, b[j][2]), acc[m][j], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            dma_wait(t + 2 < nst);                          // the next stage's panel has landed (this wave's share) before the barrier publishes it
+            dma_wait(t + RING < nst);                       // the next stage's panel has landed (this wave's share) before the barrier publishes it
         };
         using Slot0 = std::integral_constant<int, 0>;
         using Slot1 = std::integral_constant<int, 1>;
@@ -1029,7 +1040,7 @@ void stream_gemm_x3w2_kernel(const float* __restrict__ S, const u32x4* __restric
         if (t < nst) { stage(Slot0{}, t); __syncthreads(); }
 
         // D: component = 16 m + 4 kg + e, column = c16 -> f_local = WAVE_F * wave + 4 c16 + tile; components [0, 128) -> pieces0, the rest -> pieces1
-        const int64_t off = (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KH;
+        const int64_t off = (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KH;        // (BLOCK_F = NW x 64 columns)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             float* out = (hh == 0 ? pieces0 : pieces1) + off;

@@ -1066,6 +1066,30 @@ def test_two_wave_sweeps_are_bitwise_the_one_wave_form(name, data):
     b.close()
 
 
+@pytest.mark.parametrize("name", ["wide_k150", "als_wide_k150", "als_wide_k160_fro"])
+def test_wide_one_pass_sweep_with_two_waves_per_simd(name):
+    """128 < K <= 160 on one-plane data: the one-pass sweep runs its 8-wave form (stream_gemm_x3w2_kernel<10, true, 8>: two waves per SIMD,
+    512-column workgroup tiles, one stage of X in flight per wave).  Another division of the same sums: against the 4-wave form (option
+    x3_two_wave = 0) and against the float32-MFMA sweeps on the same count data; the golden (full-significand) input keeps the 4-wave form."""
+    g = make_engine(load_case(name), x_dtype="x3")
+    assert g.info().sweep_waves_per_simd == 1
+    g.close()
+    c = _count_like(load_case(name), 6.0)
+    assert float(c.X.max()) < 256
+    a = make_engine(c, x_dtype="x3")
+    b = make_engine(c, x_dtype="x3", options={"x3_two_wave": 0})
+    f = make_engine(c)
+    assert a.info().sweep_waves_per_simd == 2 and b.info().sweep_waves_per_simd == 1 and a.info().x_multi_plane_fraction == 0.0
+    for e in (a, b, f):
+        e.run(c.T, with_loss=True)
+    (Wa, Ha, _), (Wb, Hb, _), (Wf, Hf, _) = a.get_factors(), b.get_factors(), f.get_factors()
+    assert rel_fro(Wa, Wb) < 2e-5 and rel_fro(Ha, Hb) < 2e-5
+    assert rel_fro(Wa, Wf) < 5e-5 and rel_fro(Ha, Hf) < 5e-5
+    np.testing.assert_allclose(a.losses(), b.losses(), rtol=2e-5)
+    for e in (a, b, f):
+        e.close()
+
+
 @pytest.mark.parametrize("name", ["wide_k150", "wide_k200_fro", "als_wide_k160_fro", "mb_wide_k150"])
 def test_wide_one_pass_and_two_pass_sweeps_agree_with_the_reference(name):
     """128 < K <= 256 on the x3 sweeps: stream_gemm_x3w2_kernel reads X ONCE per sweep (a wave owns 64 columns x all 256 components, the

@@ -41,24 +41,29 @@ static void shape(int64_t G, int64_t N, float* X, float* P, u32x4* Pk, float* pi
             hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, P, (size_t)2 * R * 128, 2, 77u);
             const int64_t plane_stride = (R / 8) * KPA;
             hipLaunchKernelGGL(pack_panel3_wide_kernel, dim3(2048), dim3(256), 0, 0, P, P + R * 128, (int)R, KPA, Pk, plane_stride);
-            const SweepGeom g = sg_make_geom(F, R, 256 / gw, 0, 256 * gw, 0, gw);
-            if ((size_t)2 * g.nwg * g.maxp * g.bf * 128 > piece_floats) { printf("pieces buffer too small\n"); return; }
-            float* p0 = pieces; float* p1 = pieces + (size_t)g.nwg * g.maxp * g.bf * 128;
-            std::vector<float> ms;
-            for (int r = -3; r < reps; ++r) {
-                (void)hipEventRecord(e0);
-                if (data == 0) hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M16A, true>), dim3(sg_grid(g)), dim3(256), 0, 0, X, Pk, plane_stride, p0, p1, F, g, (int*)nullptr);
-                else hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M16A, false>), dim3(sg_grid(g)), dim3(256), 0, 0, X, Pk, plane_stride, p0, p1, F, g, (int*)nullptr);
-                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
-                float t; (void)hipEventElapsedTime(&t, e0, e1);
-                if (r >= 0) ms.push_back(t);
+            for (int nw = 4; nw <= (data == 0 && M16A <= 10 ? 8 : 4); nw += 4) {
+                const SweepGeom g = sg_make_geom(F, R, 256 / gw, 0, 64 * nw * gw, 0, gw);
+                if ((size_t)2 * g.nwg * g.maxp * g.bf * 128 > piece_floats) { printf("pieces buffer too small\n"); return; }
+                float* p0 = pieces; float* p1 = pieces + (size_t)g.nwg * g.maxp * g.bf * 128;
+                std::vector<float> ms;
+                for (int r = -3; r < reps; ++r) {
+                    (void)hipEventRecord(e0);
+                    if (data == 0 && nw == 8) {
+                        if constexpr (M16A <= 10) hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M16A, true, 8>), dim3(sg_grid(g)), dim3(512), 0, 0, X, Pk, plane_stride, p0, p1, F, g, (int*)nullptr);
+                    }
+                    else if (data == 0) hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M16A, true>), dim3(sg_grid(g)), dim3(256), 0, 0, X, Pk, plane_stride, p0, p1, F, g, (int*)nullptr);
+                    else hipLaunchKernelGGL((stream_gemm_x3w2_kernel<M16A, false>), dim3(sg_grid(g)), dim3(256), 0, 0, X, Pk, plane_stride, p0, p1, F, g, (int*)nullptr);
+                    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                    float t; (void)hipEventElapsedTime(&t, e0, e1);
+                    if (r >= 0) ms.push_back(t);
+                }
+                const hipError_t e = hipGetLastError();
+                if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
+                std::sort(ms.begin(), ms.end());
+                const double med = ms[ms.size() / 2];
+                printf("%-16s %-5s %d waves  grid %4d (spans %4d x %d pieces)  min %.3f med %.3f ms  %.2f TB/s  %.3f of 8 TB/s\n", data == 0 ? "count-like" : "full-significand",
+                       orient == 0 ? "W^TX" : "XH^T", nw, sg_grid(g), g.nwg, g.maxp, ms[0], med, (double)F * R * 4.0 / (med * 1e-3) / 1e12, (double)F * R * 4.0 / (med * 1e-3) / 8e12);
             }
-            const hipError_t e = hipGetLastError();
-            if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
-            std::sort(ms.begin(), ms.end());
-            const double med = ms[ms.size() / 2];
-            printf("%-16s %-5s grid %4d (spans %4d x %d pieces)  min %.3f med %.3f ms  %.2f TB/s  %.3f of 8 TB/s\n", data == 0 ? "count-like" : "full-significand",
-                   orient == 0 ? "W^TX" : "XH^T", sg_grid(g), g.nwg, g.maxp, ms[0], med, (double)F * R * 4.0 / (med * 1e-3) / 1e12, (double)F * R * 4.0 / (med * 1e-3) / 8e12);
         }
     }
 }
