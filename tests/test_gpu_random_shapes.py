@@ -181,12 +181,15 @@ def test_many_label_levels_vs_oracle(loss_type):
     np.testing.assert_allclose(losses[:, 2:], want[:, 2:], rtol=2e-3, atol=1e-6 * N)
 
 
-def _fit_vs_oracle(seed, G, N, Ku, ks, levels, loss, iters, env=None, monkeypatch=None, reg=False):
+def _fit_vs_oracle(seed, G, N, Ku, ks, levels, loss, iters, env=None, monkeypatch=None, reg=False, counts=False, expect_waves=None):
     """`iters` MU iterations of a random problem through the C ABI against the oracle's fused iteration (shared by the LDS
-    budget and wide-guidance cases below)."""
+    budget and wide-guidance cases below).  counts: small integer X (every element one bf16 plane: the one-plane sweep forms);
+    expect_waves: what alpine_info.sweep_waves_per_simd must say for the x3 engine."""
     from alpine_amd import _native as nat
     rng = np.random.default_rng(seed)
     X = rng.gamma(0.4, 2.5, size=(N, G)).astype(np.float32)
+    if counts:
+        X = np.floor(X * 3).astype(np.float32)
     Ys = []
     for C in levels:
         Y = np.zeros((N, C), dtype=np.float32)
@@ -208,6 +211,8 @@ def _fit_vs_oracle(seed, G, N, Ku, ks, levels, loss, iters, env=None, monkeypatc
         try:
             eng.upload_X_host(X)
             eng.finalize_X()
+            if mode == "x3" and expect_waves is not None:
+                assert eng.info().sweep_waves_per_simd == expect_waves, eng.info().sweep_waves_per_simd
             for i, y in enumerate(Ys):
                 eng.upload_Y(i, np.ascontiguousarray(y.T))
             eng.set_factors(W0, H0, B0)
@@ -282,6 +287,25 @@ def test_wide_models_vs_oracle(Ku, ks, levels, loss, reg):
     """128 < K <= 1024: the blocked path (kernels_wide.hpp; every update as den = A.M on the MFMA + an elementwise apply, the
     sweeps once per half) against the oracle's fused iteration, ragged G and N, x3 and f32 sweeps, loss rows included."""
     _fit_vs_oracle(300 + Ku, G=203, N=517, Ku=Ku, ks=ks, levels=levels, loss=loss, iters=3, reg=reg)
+
+
+@pytest.mark.parametrize("G,N,K,counts,waves", [
+    (1031, 4097, 150, True, 2),        # 128 < K <= 160 on one-plane data: the 8-wave one-pass sweep, ragged in both axes (3 / 9 tiles of 512, partly filled)
+    (513, 20000, 129, True, 2),        # one component in the second block; 40 column tiles of cells
+    (2049, 700, 160, True, 2),         # the largest model of that form; fewer cells than two tiles
+    (900, 3000, 161, True, 1),         # one component more: 11 tiles, the 4-wave form
+    (1031, 4097, 150, False, 1),       # full significands: the general 4-wave form
+    (777, 5000, 100, False, 2),        # 64 < K <= 128 on full significands: the two-wave sweep (x3v), ragged
+    (777, 5000, 100, True, 1),         # ... on one-plane data: x3w's one-plane form
+    (3000, 1200, 70, False, 2),        # three 32-component tiles, the last 16-component tile all padding (M16A = 5)
+    (640, 9000, 96, False, 2),         # three full tiles (M16A = 6)
+    (640, 9000, 128, False, 2),        # four full tiles (M16A = 8: no fragment prefetch)
+])
+def test_two_wave_sweeps_on_ragged_shapes_vs_oracle(G, N, K, counts, waves):
+    """Round 4's two-waves-per-SIMD sweeps (stream_gemm_x3v_kernel for 64 < K <= 128 on data with more than one plane; the 8-wave form of the
+    one-pass sweep for 128 < K <= 160 on one-plane data) and their one-wave neighbours on shapes that are not multiples of any tile, several
+    workgroup tiles wide, against the oracle's fused iteration; alpine_info says which form ran."""
+    _fit_vs_oracle(1200 + K + G % 7, G=G, N=N, Ku=K - 4, ks=[4], levels=[3], loss="kl-divergence", iters=3, reg=(K % 2 == 0), counts=counts, expect_waves=waves)
 
 
 @pytest.mark.parametrize("G,N,Ku,ks,levels,loss", [
