@@ -527,7 +527,10 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     // (wide models on the x3 sweeps: the one-pass kernel stream_gemm_x3w2_kernel, a wave owns 64 columns x all 256 components -- up to
     // 224 components: with all 16 component tiles its 256 accumulators + X ring + planes no longer fit the register file (68 - 248 B of
     // scratch per lane in the hot loop: 41 - 70 it/s at K = 256 against 69 on two passes), so K > 224 stays on the two-pass form)
-    c->wide_one_pass = c->wide && c->x3 && !c->x3_ablate && c->K <= 224;        // (K > 256: one launch per half)
+    // (the kernels that address X as a scalar row base + a 32-bit lane offset -- x3w2, x3v -- need 24 rows of the longer axis to fit 2^32 bytes:
+    // shards of more than 2^25 cells (or genes) stay on the kernels with 64-bit lane addresses)
+    const bool lane32_ok = std::max(Gp, Np) <= ((int64_t)1 << 25);
+    c->wide_one_pass = c->wide && c->x3 && !c->x3_ablate && c->K <= 224 && lane32_ok;        // (K > 256: one launch per half)
     const int bf_default = c->x3 ? (c->wide_one_pass ? 256 : (c->KT <= 2 ? 1024 : 512)) : c->sweep_waves * SG_WAVE_F;
     piece_floats(bf_default, &c->piecesA_cap, &c->piecesB_cap);
     if (c->wide && c->x3 && !c->x3_ablate) piece_floats(c->wide_one_pass ? 512 : 256, &c->piecesA_cap, &c->piecesB_cap);    // (alpine_debug_set_option "wide_one_pass")
@@ -857,7 +860,7 @@ extern "C" int alpine_finalize_X(alpine_ctx* c)
         // library's iteration (tools/option_ab.py, engines interleaved, profiles/r04/option_ab_*.txt) cfg4's share on full significands
         // 5.54 -> 5.25 ms, on one-plane counts level with x3w's one-plane form (3.50 / 3.53 vs 3.51 / 3.58 ms: inside the spread between
         // two engines of the SAME kind), which therefore keeps its kernel.  x3_two_wave = 1 (option): the one-plane form of x3v as well.
-        c->x3_two_wave = c->x3 && !c->wide && c->KT >= 3 && !c->x3_ablate && c->x3_variant < 0 &&
+        c->x3_two_wave = c->x3 && !c->wide && c->KT >= 3 && !c->x3_ablate && c->x3_variant < 0 && std::max(c->Gp, c->Np) <= ((int64_t)1 << 25) &&
                          (c->x3_two_wave_opt == 1 || (c->x3_two_wave_opt < 0 && !c->x_one_plane));
         if (c->x3_two_wave) c->x3_wide = true;
         // 128 < K <= 160 on one-plane data: the 8-wave form of the one-pass sweep (two waves per SIMD, 512-column workgroup tiles)
@@ -2243,7 +2246,7 @@ extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int valu
     else if (n == "x3_two_wave") { if (value < -1 || value > 1) return fail(c, ALPINE_ERR_BAD_ARG, "x3_two_wave must be -1, 0 or 1"); c->x3_two_wave_opt = value; }
     else if (n == "wide_one_pass") {
         if (!c->wide || !c->x3 || c->x3_ablate) return 0;     // only wide models on the x3 sweeps have the two forms
-        c->wide_one_pass = value != 0;
+        c->wide_one_pass = value != 0 && std::max(c->Gp, c->Np) <= ((int64_t)1 << 25);
         c->wide_two_wave = false;                            // (alpine_finalize_X decides again)
         apply_sweep_geometry(c, c->wide_one_pass ? 256 : 512);
     }
