@@ -494,10 +494,13 @@ static int create_impl(alpine_ctx* c, const alpine_config* cfg, const Geometry& 
     // piece traffic (every workgroup flushes bf x KP accumulators whatever the shard size: 67 MB per sweep at 1024 columns,
     // written and read back) outweighs the doubled panel re-reads of 512-column tiles.  Interleaved A/B, ms per iteration, 512 vs
     // 1024 columns: 25 000 cells 0.7436 vs 0.7510, 50 000 cells 1.360 vs 1.399, 100 000 cells 2.680 vs 2.640, 200 000 cells
-    // +0.8 %; on the 16x16x32 form (x3w) 512 columns LOSE at 25 000 cells (0.794 vs 0.779).  So: 512 columns for shards of
-    // <= 65 536 cells unless alpine_finalize_X selects x3w.  ALPINE_HIP_X3_NARROW=0|1 forces one form.
+    // +0.8 %; on the 16x16x32 form (x3w) 512 columns LOSE at 25 000 cells (0.794 vs 0.779).  So: 512 columns for small shards
+    // unless alpine_finalize_X selects x3w.  Round 4, with teams (the panel of a 512-column tile is shared by its team through L2, which
+    // takes most of the narrow tiles' extra panel traffic away; tools/option_ab.py, two engines per form, profiles/r04/narrow_tiles_ab.txt):
+    // 25 000 cells 0.707 / 0.720 vs 0.757 / 0.757 ms, 50 000 1.330 / 1.361 vs 1.422 / 1.383, 100 000 2.605 / 2.596 vs 2.687 / 2.650,
+    // 200 000 5.220 / 5.224 vs 5.103 / 5.183: the limit moved from 65 536 to 131 072 cells.  Option "x3_narrow" forces one form.
     if (const char* e = knob_env("ALPINE_HIP_X3_NARROW")) { c->x3_narrow_pref = (e[0] == '1'); c->x3_narrow_forced = true; }
-    else c->x3_narrow_pref = cfg->n_cells <= 65536;
+    else c->x3_narrow_pref = cfg->n_cells <= 131072;
     if (c->x3_ablate || !c->x3 || c->KT > 2) c->x3_narrow_pref = false;   // (the diagnostics build's ablated kernels are 1024-column only)
     c->batch_cap = cfg->batch_capacity;
     c->split_a_hint = cfg->split_a; c->split_b_hint = cfg->split_b;
@@ -2226,7 +2229,7 @@ extern "C" int alpine_debug_set_xcd_bias(alpine_ctx* c, int per_mille)
 //   "sg_variant" 0|1|2   pipeline shape of the float32-MFMA sweep
 //   "x3_variant" -1|0|2  matrix instruction of the x3 sweeps: 0 = 32x32x16, 2 = 16x16x32 general form, -1 = from the data; BEFORE alpine_finalize_X
 //   "wide_one_pass" 0|1  128 < K <= 256 on the x3 sweeps: one pass over X per sweep (default up to K = 224) or one per component half; BEFORE alpine_finalize_X
-//   "x3_narrow" 0|1      512-column workgroup tiles at K <= 64 (default: shards of <= 65 536 cells on the 32x32x16 form); BEFORE alpine_finalize_X
+//   "x3_narrow" 0|1      512-column workgroup tiles at K <= 64 (default: shards of <= 131 072 cells on the 32x32x16 form); BEFORE alpine_finalize_X
 //   "x3_two_wave" -1|0|1 64 < K <= 128 on the x3 sweeps: the two-waves-per-SIMD kernel (default) or the one-wave forms; BEFORE alpine_finalize_X
 extern "C" int alpine_debug_set_option(alpine_ctx* c, const char* name, int value)
 {
