@@ -382,7 +382,7 @@ static void apply_sweep_geometry(alpine_ctx* c, int bf)
 
 static int team_width(const alpine_ctx* c, int64_t F, int bf_wg, int forced)
 {
-    if (!c->x3 || forced > 0) return 1;
+    if (!(c->x3 || c->bf16) || forced > 0) return 1;
     if (c->team_force == 0 && !c->team_ok) return 1;
     const int64_t tiles = (F + bf_wg - 1) / bf_wg;
     auto admissible = [&](int gw) { return gw >= 1 && c->slots % (8 * gw) == 0; };
@@ -398,7 +398,7 @@ static int team_width(const alpine_ctx* c, int64_t F, int bf_wg, int forced)
 static SweepGeom make_geom(const alpine_ctx* c, int64_t F, int64_t R, int forced, int bf_wg, int bias_pm, int gw)
 {
     if (gw <= 0) gw = team_width(c, F, bf_wg, forced);
-    else if (!c->x3 || forced > 0 || c->slots % (8 * gw) != 0) gw = 1;
+    else if (!(c->x3 || c->bf16) || forced > 0 || c->slots % (8 * gw) != 0) gw = 1;
     // K > 64 in teams: the even/odd bias the placement probe chose for the team-less division costs 2 % there (tools/team_ab.py, one
     // engine, interleaved: K = 105 at 125 000 cells 3.630 ms per iteration with -40 per mille, 3.547 without; at K = 60 the bias still
     // pays with teams: 5.284 vs 5.340 ms) -- an explicitly requested bias (environment, alpine_debug_set_xcd_bias) is left alone
@@ -1059,7 +1059,7 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
     int* xcc_out = c->probe_placement ? c->xcc_dev : nullptr;
 #define BF_ARGS S, (which == 0 ? c->x_plane_ng : c->x_plane_gn), panel, p_plane, master, pieces, g, xcc_out
 #define BF_LAUNCH(NPX, NPP) do { \
-        if (g.bf == 8 * SG_WAVE_F) {          /* 8 waves: K <= 64 only (create_impl) */ \
+        if (g.bf == 8 * SG_WAVE_F * g.gw) {   /* 8 waves: K <= 64 only (create_impl); g.bf = the TEAM tile */ \
             if (c->KT == 1) hipLaunchKernelGGL((stream_gemm_bf16_kernel<1, NPX, NPP, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
             else            hipLaunchKernelGGL((stream_gemm_bf16_kernel<2, NPX, NPP, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
         } else { \

@@ -254,7 +254,10 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     SgWalk walk;
-    sg_walk_init(walk, g, blockIdx.x);
+    int team, member;                                               // round 4: workgroups in teams of one XCD (SweepGeom::gw, kernels.hpp): the members of a team walk
+    sg_team_of_block(g, blockIdx.x, team, member);                  // the same contraction rows on adjacent column tiles and share the panel through that XCD's L2
+    sg_walk_init(walk, g, team);
+    constexpr int BLOCK_F = NW * SG_WAVE_F;
     const int64_t f_stride8 = (int64_t)g.F * 8;                     // bf16 elements between consecutive 8-row blocks of S
 
     u32x4 preg[PV];                                                 // NPP == 1: staged bf16 granules
@@ -265,7 +268,9 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
     int64_t slot;
     while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
         const int nst = (r_end - r_begin) / BF_ROWS;
-        const int f0 = (ft * NW + wave) * SG_WAVE_F;
+        const int wt = ft * g.gw + member;                 // this workgroup's BLOCK_F-wide tile (ft = the team's tile)
+        if ((int64_t)wt * BLOCK_F >= g.F) continue;        // a member past the last column of a partly filled team tile: nothing to do (block-uniform)
+        const int f0 = (wt * NW + wave) * SG_WAVE_F;
         const bool active = f0 < g.F;
 
         constexpr int SETS = (BF_ROWS / 8) * KP;                   // (8-row block, column) granule positions of one stage
@@ -376,7 +381,7 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
         bf_stage<KT, NPX, NPP, BF_RING, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = 128*wave + 32*j + c
-        float* out = pieces + (slot * (NW * SG_WAVE_F) + wave * SG_WAVE_F) * KP;
+        float* out = pieces + (slot * g.bf + member * BLOCK_F + wave * SG_WAVE_F) * KP;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x16* d[KT];

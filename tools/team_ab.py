@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--cells", type=int, default=None)
     ap.add_argument("--x-scale", type=float, default=1.0)
+    ap.add_argument("--dtype", default="x3", choices=["x3", "bf16", "split"])
     ap.add_argument("--variants", default="1:p,0:p,0:0,8:0,4:0,2:0")
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
@@ -35,7 +36,7 @@ def main():
     lev = [2] * len(kcov)
     W0, H0, B0 = draw_initial_factors(42, 1e-6, G, N, kcov + [ku], lev)
     eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=lev, lam=[1e3] * len(kcov),
-                              orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype="x3")
+                              orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype=a.dtype)
     for off, chunk in synth_counts_device_chunks(N, G, rank=ku, seed=0, device=dev, chunk_cells=8192):
         if a.x_scale != 1.0:
             chunk = (chunk * a.x_scale).contiguous()
