@@ -152,6 +152,10 @@ int main(int argc, char** argv)
         shape<2, 1, 4>(G, 25088, X, P, pieces, piece_floats, out, ref, reps,
                        {{"x3w", 0, 1}, {"x3 (32x32x16)", 1, 1}, {"x3 teams of 2", 1, 2}, {"x3 teams of 4", 1, 4}, {"x3 teams of 8", 1, 8}, {"x3v", 4, 1}, {"x3v teams of 2", 4, 2}, {"x3v teams of 4", 4, 4},
                         {"x3v teams of 8", 4, 8}, {"x3v one-plane teams of 4", 5, 4}, {"x3 (again)", 1, 1}});
+    if (which & 128)    // K = 60 at 200 000 cells on 512-column tiles (the library takes 1024-column tiles there): x3 / x3v with teams
+        shape<2, 1, 4>(G, 200064, X, P, pieces, piece_floats, out, ref, reps,
+                       {{"x3w", 0, 1}, {"x3 (32x32x16)", 1, 1}, {"x3 teams of 4", 1, 4}, {"x3 teams of 8", 1, 8}, {"x3 teams of 16", 1, 16}, {"x3v", 4, 1}, {"x3v teams of 4", 4, 4},
+                        {"x3v teams of 8", 4, 8}, {"x3v teams of 16", 4, 16}, {"x3v one-plane teams of 8", 5, 8}, {"x3 (again)", 1, 1}});
     if (which & 2)      // BASELINE config 3: K = 60
         shape<2, 2, 4>(G, 200064, X, P, pieces, piece_floats, out, ref, reps,
                        {{"x3 (round 3)", 1, 1}, {"x3 teams of 2", 1, 2}, {"x3 teams of 4", 1, 4}, {"x3 teams of 8", 1, 8}, {"x3 teams of 16", 1, 16},
