@@ -1124,7 +1124,7 @@ static int launch_sweep(alpine_ctx* c, const SweepGeom& g, const float* S, const
 #define X3W_LAUNCH1(KT_) do {     /* every element of X is exactly one bf16 plane (census): the form without split and test */ \
                 if (pad_tile) hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, 1, 2 * KT_ - 1, true>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); \
                 else hipLaunchKernelGGL((stream_gemm_x3w_kernel<KT_, 1, 2 * KT_, true>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, S, P, pieces, ldS, gx, xcc_out); } while (0)
-            const bool one_plane = c->x_one_plane && !c->wide && c->x3_variant < 0;
+            const bool one_plane = c->x_one_plane && c->x3_variant < 0;        // (wide models: the full and the 7-tile component blocks; partly filled last blocks take X3W_PART above)
             switch (c->KT) {
                 case 1: if (c->x3_narrow) X3W_LAUNCH(1, 1); else X3W_LAUNCH(1, 2); break;
                 case 2: if (c->x3_narrow) X3W_LAUNCH(2, 1); else X3W_LAUNCH(2, 2); break;
