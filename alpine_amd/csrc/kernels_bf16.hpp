@@ -167,8 +167,8 @@ void pack_split_kernel(const float* __restrict__ src, int64_t ld_src, int rows, 
 // (one 512-thread workgroup per CU, 1024-column tiles) halves the panel re-reads of NW = 4.  One
 // k-step = 16 rows = one v_mfma_f32_32x32x16_bf16 depth; per k-step and X plane a wave issues 4 loads of 1 KiB.  The
 // X ring holds BF_RING k-steps (16 KiB per wave in flight in every variant); one panel stage per ring pass.
-template <int KT, int NPX, int NPP, int BF_RING, bool LAST>
-__device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RING][NPX][4], const unsigned short* __restrict__ lrow,
+template <int KT, int NPX, int NPP, int BF_RING, bool LAST, int NJ = 4>
+__device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][NJ], u32x4 (&x)[BF_RING][NPX][NJ], const unsigned short* __restrict__ lrow,
                                          const unsigned short* __restrict__ xnext, int64_t f_stride8, int64_t x_plane, int lds_plane)
 {
     // Order inside a k-step: tile j outermost, so that the X register of tile j is dead after its NPP*KT (one-plane X)
@@ -197,7 +197,7 @@ __device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RIN
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int pp = 0; pp < NPP; ++pp) {
 #pragma unroll
@@ -209,7 +209,7 @@ __device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RIN
                                                                                 __builtin_bit_cast(bf16x8, x[p][xp][j]), acc[m][j], 0, 0, 0);
                     }
                 }
-                if (NB == 1 && j == 3 && p + 1 < BF_RING) {
+                if (NB == 1 && j == NJ - 1 && p + 1 < BF_RING) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < KT; ++m) a[0][pp][m] = lda(p + 1, pp, m);
@@ -227,7 +227,11 @@ __device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][4], u32x4 (&x)[BF_RIN
     }
 }
 
-template <int KT, int NPX, int NPP, int NW>
+// NJ = 32-column sub-tiles per wave: 4 (a wave owns 128 columns x all KP: 256 accumulator registers at KT = 4, one wave per SIMD) or -- round 4,
+// K > 64 -- 2 with NW = 8: the same 512-column workgroup tile from eight 64-column waves, TWO per SIMD (128 accumulator registers): the K > 64 forms
+// ran at 0.41 of the HBM roof on one-plane X (3 MFMAs per load, issued by one wave per SIMD between its own loads and LDS reads).  The flush
+// scratch of eight waves (135 KB at KT = 4) then shares its LDS with the panel stages (one more barrier per span).
+template <int KT, int NPX, int NPP, int NW, int NJ = 4>
 __global__ __launch_bounds__(64 * NW, (KT <= 2 && NW == 4 ? 2 : 1))
 void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_plane, const unsigned short* __restrict__ P,
                              int64_t p_plane, const float* __restrict__ Pf, float* __restrict__ pieces, SweepGeom g, int* __restrict__ xcc_out)
@@ -246,8 +250,12 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
     constexpr int STAGE_BF16 = BF_ROWS * KP;                        // bf16 elements of one panel stage, per plane
     constexpr int GRAN = STAGE_BF16 / 8;                            // 16-byte granules per plane per stage
     constexpr int PV = NPP == 1 ? (GRAN + NT - 1) / NT : 1;     // granules per thread per stage (bf16 panel copy)
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2][NPP * STAGE_BF16];
-    __shared__ __attribute__((aligned(16))) float flush_tr[NW][32 * (KP + 4)];
+    constexpr int WAVE_F = 32 * NJ;
+    constexpr bool ALIAS = NJ != 4;                                 // the flush scratch overlays the panel stages
+    constexpr int LDS_PANEL_BYTES = 2 * NPP * STAGE_BF16 * 2, LDS_FLUSH_BYTES = NW * 32 * (KP + 4) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ALIAS ? (LDS_PANEL_BYTES > LDS_FLUSH_BYTES ? LDS_PANEL_BYTES : LDS_FLUSH_BYTES) : LDS_PANEL_BYTES + LDS_FLUSH_BYTES];
+    unsigned short (*lds)[NPP * STAGE_BF16] = reinterpret_cast<unsigned short (*)[NPP * STAGE_BF16]>(smem);
+    float (*flush_tr)[32 * (KP + 4)] = reinterpret_cast<float (*)[32 * (KP + 4)]>(smem + (ALIAS ? 0 : LDS_PANEL_BYTES));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,12 +265,12 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
     int team, member;                                               // round 4: workgroups in teams of one XCD (SweepGeom::gw, kernels.hpp): the members of a team walk
     sg_team_of_block(g, blockIdx.x, team, member);                  // the same contraction rows on adjacent column tiles and share the panel through that XCD's L2
     sg_walk_init(walk, g, team);
-    constexpr int BLOCK_F = NW * SG_WAVE_F;
+    constexpr int BLOCK_F = NW * WAVE_F;
     const int64_t f_stride8 = (int64_t)g.F * 8;                     // bf16 elements between consecutive 8-row blocks of S
 
     u32x4 preg[PV];                                                 // NPP == 1: staged bf16 granules
     float pf[NPP == 1 ? 1 : ((BF_ROWS / 8) * KP + NT - 1) / NT][8];   // NPP == 3: staged float32 panel values
-    u32x4 x[BF_RING][NPX][4];
+    u32x4 x[BF_RING][NPX][NJ];
 
     int ft, r_begin, r_end;
     int64_t slot;
@@ -270,7 +278,7 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
         const int nst = (r_end - r_begin) / BF_ROWS;
         const int wt = ft * g.gw + member;                 // this workgroup's BLOCK_F-wide tile (ft = the team's tile)
         if ((int64_t)wt * BLOCK_F >= g.F) continue;        // a member past the last column of a partly filled team tile: nothing to do (block-uniform)
-        const int f0 = (wt * NW + wave) * SG_WAVE_F;
+        const int f0 = (wt * NW + wave) * WAVE_F;
         const bool active = f0 < g.F;
 
         constexpr int SETS = (BF_ROWS / 8) * KP;                   // (8-row block, column) granule positions of one stage
@@ -336,14 +344,15 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
                 if (t + 2 < nst) load_p(t + 2);
                 __syncthreads();
             }
+            if (ALIAS) __syncthreads();                    // (the computing waves' barrier before their flush)
             continue;
         }
 
-        f32x16 acc[KT][4];
+        f32x16 acc[KT][NJ];
 #pragma unroll
         for (int m = 0; m < KT; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
@@ -358,7 +367,7 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
 #pragma unroll
             for (int xp = 0; xp < NPX; ++xp)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xrow + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -368,22 +377,23 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
             store_p((t + 1) & 1);
             load_p(t + 2);
             __builtin_amdgcn_sched_barrier(0);
-            bf_stage<KT, NPX, NPP, BF_RING, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
+            bf_stage<KT, NPX, NPP, BF_RING, false, NJ>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
             __syncthreads();
         }
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            bf_stage<KT, NPX, NPP, BF_RING, false>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
+            bf_stage<KT, NPX, NPP, BF_RING, false, NJ>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
             __syncthreads();
             ++t;
         }
-        bf_stage<KT, NPX, NPP, BF_RING, true>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
+        bf_stage<KT, NPX, NPP, BF_RING, true, NJ>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
+        if (ALIAS) __syncthreads();                        // every wave has read its last panel stage: the flush scratch may overwrite it
 
-        // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = 128*wave + 32*j + c
-        float* out = pieces + (slot * g.bf + member * BLOCK_F + wave * SG_WAVE_F) * KP;
+        // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = WAVE_F*wave + 32*j + c
+        float* out = pieces + (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KP;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const f32x16* d[KT];
 #pragma unroll
             for (int m = 0; m < KT; ++m) d[m] = &acc[m][j];

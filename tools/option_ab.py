@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--cells", type=int, default=None)
     ap.add_argument("--x-scale", type=float, default=1.0)
+    ap.add_argument("--dtype", default="x3", choices=["x3", "f32", "bf16", "split"])
     ap.add_argument("--variants", default="x3_two_wave=0,")
     ap.add_argument("--copies", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=4)
@@ -40,7 +41,7 @@ def main():
         for v in a.variants.split(","):
             opts, _, tw = v.partition("@")
             eng = _native.NativeShard(n_genes=G, n_cells=N, n_components=ku, cov_components=kcov, cov_levels=lev, lam=[1e3] * len(kcov),
-                                      orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype="x3")
+                                      orth_W=wl["orth_W"], alpha_W=wl["alpha_W"], l1_ratio_W=wl["l1_ratio_W"], x_dtype=a.dtype)
             for kv in filter(None, opts.split("+")):
                 k, val = kv.split("=")
                 eng.debug_set_option(k, int(val))
