@@ -69,8 +69,8 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # (0.5 s of device time at the headline size: past the first ~50 ms, in which the clock still settles)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--cells", type=int, default=None, help="override the number of cells")
     ap.add_argument("--genes", type=int, default=None)
