@@ -227,12 +227,12 @@ np.savez({out!r}, W=np.concatenate(m.matrices["Ws"], axis=1), H=np.concatenate(m
 
 
 @pytest.mark.parametrize("case_name,devices", [("kl_2cov_nan", [0, 0]), ("counts_2cov", [0, 0, 0]), ("als_fro_2cov", [0, 0]), ("mb_weighted", [0, 0]),
-                                               ("wide_k150", [0, 0]), ("k105", [0, 0])])
+                                               ("wide_k150", [0, 0]), ("k105", [0, 0]), ("wide_k300", [0, 0, 0])])
 def test_drop_in_fit_with_devices_in_one_process(case_name, devices, tmp_path):
     """ALPINE(devices=[...]).fit(adata): one process, one engine and one host thread per listed GPU, the library's communicator over them
     (alpine_comm_init_all), no launcher and no torch.distributed -- the reference's one blocking call (main.py:82-147).  Rehearsed on one
     GPU: the engines share cuda:0 (ALPINE_AMD_TEST_SHARED_DEVICE=1) and the stand-in carries the bytes.  Full batch, block-coordinate
-    branch, weighted mini-batches (the epoch's index stream drawn once, every engine takes its cells), K > 64 and K > 128."""
+    branch, weighted mini-batches (the epoch's index stream drawn once, every engine takes its cells), K > 64, K > 128 and K > 256."""
     import sys
     c = load_case(case_name)
     out = str(tmp_path / "r.npz")
