@@ -1062,7 +1062,7 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
         if (g.bf == 8 * SG_WAVE_F * g.gw) {   /* 8 waves: K <= 64 only (create_impl); g.bf = the TEAM tile */ \
             if (c->KT == 1) hipLaunchKernelGGL((stream_gemm_bf16_kernel<1, NPX, NPP, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
             else            hipLaunchKernelGGL((stream_gemm_bf16_kernel<2, NPX, NPP, 8>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
-        } else if (c->KT >= 3 && c->x3_two_wave_opt != 0) {      /* K > 64: eight 64-column waves, two per SIMD (option "x3_two_wave" 0: the 4-wave form) */ \
+        } else if (c->KT >= 3 && c->x3_two_wave_opt != 0 && std::max(c->Gp, c->Np) <= ((int64_t)1 << 25)) {   /* K > 64: eight 64-column waves, two per SIMD, 32-bit lane offsets (option "x3_two_wave" 0: the 4-wave form) */ \
             if (c->KT == 3) hipLaunchKernelGGL((stream_gemm_bf16_kernel<3, NPX, NPP, 8, 2>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
             else            hipLaunchKernelGGL((stream_gemm_bf16_kernel<4, NPX, NPP, 8, 2>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, BF_ARGS); \
         } else { \

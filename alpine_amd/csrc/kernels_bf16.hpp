@@ -155,6 +155,25 @@ void pack_split_kernel(const float* __restrict__ src, int64_t ld_src, int rows, 
     }
 }
 
+// A wave-uniform 64-bit address as a SCALAR register pair (the compiler's divergence analysis already knows most of these are uniform; the
+// readfirstlane pins it), and loads through it in the saddr form of global_load: uniform base + ONE 32-bit lane offset.  Per-lane 64-bit
+// addresses of 8 rows (and of up to 12 panel pieces), which the compiler hoists out of a stage loop as loop invariants, cost 16 - 40
+// vector registers in the kernels that have none to spare -- spilled, and re-loaded in the loop behind an s_waitcnt vmcnt(0).
+__device__ __forceinline__ unsigned long long x3_uniform_u64(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32)
+           | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+template <typename V>
+__device__ __forceinline__ V sg_load_nt_saddr(const char* uniform_row, unsigned lane_off)
+{
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef const __attribute__((address_space(1))) V* gv_p;
+    const unsigned long long urow = x3_uniform_u64(reinterpret_cast<unsigned long long>(uniform_row));
+    asm volatile("" : "+v"(lane_off));          // (opaque: keeps the compiler from folding the lane offset into a hoisted per-lane 64-bit base)
+    return __builtin_nontemporal_load(reinterpret_cast<gv_p>(reinterpret_cast<gchar_p>(urow) + lane_off));
+}
+
 // ----------------------------------------------------------------------------------------------
 // stream_gemm on the bf16 matrix pipe: out[f][k] = sum_r S[r][f] * P[r][k] with S given as NPX bf16 planes and P as NPP
 // bf16 planes (all k-packed).  Products of planes whose magnitudes matter at float32 precision are accumulated into the
@@ -167,9 +186,11 @@ void pack_split_kernel(const float* __restrict__ src, int64_t ld_src, int rows, 
 // (one 512-thread workgroup per CU, 1024-column tiles) halves the panel re-reads of NW = 4.  One
 // k-step = 16 rows = one v_mfma_f32_32x32x16_bf16 depth; per k-step and X plane a wave issues 4 loads of 1 KiB.  The
 // X ring holds BF_RING k-steps (16 KiB per wave in flight in every variant); one panel stage per ring pass.
-template <int KT, int NPX, int NPP, int BF_RING, bool LAST, int NJ = 4>
+// x_lane != ~0u: xnext is a WAVE-UNIFORM base (the tile's first column of the stage's first 8-row block) and the lane's part is the
+// 32-bit byte offset x_lane (saddr loads: the two-waves-per-SIMD forms, which have no registers for per-lane 64-bit row addresses)
+template <int KT, int NPX, int NPP, int BF_RING, bool LAST, int NJ = 4, bool SADDR = false>
 __device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][NJ], u32x4 (&x)[BF_RING][NPX][NJ], const unsigned short* __restrict__ lrow,
-                                         const unsigned short* __restrict__ xnext, int64_t f_stride8, int64_t x_plane, int lds_plane)
+                                         const unsigned short* __restrict__ xnext, int64_t f_stride8, int64_t x_plane, int lds_plane, unsigned x_lane = 0u)
 {
     // Order inside a k-step: tile j outermost, so that the X register of tile j is dead after its NPP*KT (one-plane X)
     // MFMAs and is refilled at once -- a ring slot is in flight for (ring period - one tile's MFMAs) instead of (ring
@@ -219,8 +240,12 @@ __device__ __forceinline__ void bf_stage(f32x16 (&acc)[KT][NJ], u32x4 (&x)[BF_RI
             __builtin_amdgcn_sched_barrier(0);
             if (!LAST) {
 #pragma unroll
-                for (int xp = 0; xp < NPX; ++xp)
-                    x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xnext + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
+                for (int xp = 0; xp < NPX; ++xp) {
+                    if constexpr (SADDR)
+                        x[p][xp][j] = sg_load_nt_saddr<u32x4>(reinterpret_cast<const char*>(xnext + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)), x_lane);
+                    else
+                        x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xnext + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -357,7 +382,10 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
                 for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
         // this lane's granule of (row block r_begin/8 + h, column f0 + c); tile j is +32 columns, k-step p is +2 blocks
-        const unsigned short* xrow = S + ((int64_t)(r_begin / 8 + h) * g.F + f0 + c) * 8;
+        // (SADDR: xrow is the wave-uniform part -- row block r_begin/8, column f0 -- and x_lane the lane's byte offset, < 2^32 for F <= 2^27)
+        constexpr bool SADDR = NJ != 4;
+        const unsigned x_lane = (unsigned)(((int64_t)h * g.F + c) * 16);
+        const unsigned short* xrow = SADDR ? S + ((int64_t)(r_begin / 8) * g.F + f0) * 8 : S + ((int64_t)(r_begin / 8 + h) * g.F + f0 + c) * 8;
         const int64_t x_stage = (int64_t)(BF_ROWS / 8) * f_stride8;
         const int lds_lane = (h * KP + c) * 8;
 
@@ -367,8 +395,12 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
 #pragma unroll
             for (int xp = 0; xp < NPX; ++xp)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xrow + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (SADDR)
+                        x[p][xp][j] = sg_load_nt_saddr<u32x4>(reinterpret_cast<const char*>(xrow + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)), x_lane);
+                    else
+                        x[p][xp][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xrow + xp * x_plane + (2 * p) * f_stride8 + j * (32 * 8)));
+                }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
 
@@ -377,17 +409,17 @@ void stream_gemm_bf16_kernel(const unsigned short* __restrict__ S, int64_t x_pla
             store_p((t + 1) & 1);
             load_p(t + 2);
             __builtin_amdgcn_sched_barrier(0);
-            bf_stage<KT, NPX, NPP, BF_RING, false, NJ>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
+            bf_stage<KT, NPX, NPP, BF_RING, false, NJ, SADDR>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16, x_lane);
             __syncthreads();
         }
         if (t + 1 < nst) {
             store_p((t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            bf_stage<KT, NPX, NPP, BF_RING, false, NJ>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16);
+            bf_stage<KT, NPX, NPP, BF_RING, false, NJ, SADDR>(acc, x, &lds[t & 1][lds_lane], xrow + (t + 1) * x_stage, f_stride8, x_plane, STAGE_BF16, x_lane);
             __syncthreads();
             ++t;
         }
-        bf_stage<KT, NPX, NPP, BF_RING, true, NJ>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16);
+        bf_stage<KT, NPX, NPP, BF_RING, true, NJ, SADDR>(acc, x, &lds[t & 1][lds_lane], xrow, f_stride8, x_plane, STAGE_BF16, x_lane);
         if (ALIAS) __syncthreads();                        // every wave has read its last panel stage: the flush scratch may overwrite it
 
         // D: row = k within tile m (8q + 4h + e), column = lane & 31 -> f_local = WAVE_F*wave + 32*j + c

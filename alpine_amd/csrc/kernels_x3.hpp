@@ -68,23 +68,8 @@ __device__ __forceinline__ void x3_split8_scalar(const float (&v)[8], u32x4 (&b)
     }
 }
 
-// A wave-uniform 64-bit address as a SCALAR register pair (the compiler's divergence analysis already knows most of these are uniform; the
-// readfirstlane pins it), and loads through it in the saddr form of global_load: uniform base + ONE 32-bit lane offset.  Per-lane 64-bit
-// addresses of 8 rows (and of up to 12 panel pieces), which the compiler hoists out of a stage loop as loop invariants, cost 16 - 40
-// vector registers in the kernels that have none to spare -- spilled, and re-loaded in the loop behind an s_waitcnt vmcnt(0).
-__device__ __forceinline__ unsigned long long x3_uniform_u64(unsigned long long v)
-{
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32)
-           | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-}
-__device__ __forceinline__ f32x4 x3_load_nt_saddr(const char* uniform_row, unsigned lane_off)
-{
-    typedef const __attribute__((address_space(1))) char* gchar_p;
-    typedef const __attribute__((address_space(1))) f32x4* gf32x4_p;
-    const unsigned long long urow = x3_uniform_u64(reinterpret_cast<unsigned long long>(uniform_row));
-    asm volatile("" : "+v"(lane_off));          // (opaque: keeps the compiler from folding the lane offset into a hoisted per-lane 64-bit base)
-    return __builtin_nontemporal_load(reinterpret_cast<gf32x4_p>(reinterpret_cast<gchar_p>(urow) + lane_off));
-}
+// (x3_uniform_u64 / sg_load_nt_saddr: kernels_bf16.hpp)
+__device__ __forceinline__ f32x4 x3_load_nt_saddr(const char* uniform_row, unsigned lane_off) { return sg_load_nt_saddr<f32x4>(uniform_row, lane_off); }
 
 // One panel stage = X3_RING k-steps.  Per k-step: A fragments of all three panel planes (double-buffered over k-steps),
 // then per 128-column half: 4 x (split one tile's 8 x float32 into planes, 6*KT MFMAs), then the half's 8 loads are
