@@ -1470,7 +1470,7 @@ static int phase2(alpine_ctx* c, const CellView& v, bool update, bool finalize)
 }
 
 
-// ---------------------------------------------------------------------------------- wide models (128 < K <= 256, kernels_wide.hpp)
+// ---------------------------------------------------------------------------------- wide models (128 < K <= 1024, kernels_wide.hpp)
 static float* wide_half(float* base, int64_t rows_pad, int h) { return base + (int64_t)h * rows_pad * WIDE_KH; }
 static float* wide_block(const alpine_ctx* c, float* base, int a, int b) { return base + (int64_t)(a * c->NH + b) * WIDE_KH * WIDE_KH; }
 // 16-component tiles of half h that hold real components (0 = all of them): only the last half is partly filled
