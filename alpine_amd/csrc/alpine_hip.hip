@@ -1068,6 +1068,20 @@ static int launch_sweep_bf16(alpine_ctx* c, int which, const SweepGeom& g_in)
         } else { \
             DISPATCH_KT(c->KT, hipLaunchKernelGGL((stream_gemm_bf16_kernel<KT_, NPX, NPP, 4>), dim3(sweep_grid(g)), dim3(256), 0, c->stream, BF_ARGS)); \
         } } while (0)
+    // exact-plane storage at K > 64: the two-wave sweep on the 16x16x32 instruction (stream_gemm_bf16v_kernel, kernels_x3.hpp; 32-bit lane offsets:
+    // axes up to 2^25; option "x3_two_wave" 0: the 32x32x16 kernel)
+    if (c->split && c->KT >= 3 && c->x3_two_wave_opt != 0 && std::max(c->Gp, c->Np) <= ((int64_t)1 << 25) && g.bf == 512 * g.gw) {
+        const bool pad_tile = c->K <= c->KP - 16;
+        const int64_t xpl = which == 0 ? c->x_plane_ng : c->x_plane_gn;
+#define BFV(KT_, M_) do { \
+            if (c->npx == 1) hipLaunchKernelGGL((stream_gemm_bf16v_kernel<KT_, M_, 1>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, S, xpl, master, pieces, g, xcc_out); \
+            else hipLaunchKernelGGL((stream_gemm_bf16v_kernel<KT_, M_, 2>), dim3(sweep_grid(g)), dim3(512), 0, c->stream, S, xpl, master, pieces, g, xcc_out); } while (0)
+        if (c->KT == 3) { if (pad_tile) BFV(3, 5); else BFV(3, 6); }
+        else { if (pad_tile) BFV(4, 7); else BFV(4, 8); }
+#undef BFV
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     if (!c->split) { BF_LAUNCH(1, 1); }
     else if (c->npx == 1) { BF_LAUNCH(1, 3); }
     else { BF_LAUNCH(2, 3); }

@@ -775,6 +775,178 @@ void stream_gemm_x3v_kernel(const float* __restrict__ S, const float* __restrict
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
+// The two-wave sweep on X STORED as exact bf16 planes (x_dtype = "split": NPX = 1 or 2 planes, k-packed [row / 8][F][8], kernels_bf16.hpp) for
+// 64 < K <= 128 ("bf16v", round 4).  stream_gemm_bf16_kernel multiplies 32 x 32 x 16 tiles -- all 128 padded components of a K = 105 model, 256 or
+// 128 accumulator registers per wave -- and is matrix-pipe-bound there (1.36 ms per sweep of cfg4's share for 5 GB of X: 0.46 of the roof).  This is
+// stream_gemm_x3v_kernel with the X path replaced: a lane's 16-byte granule of the k-packed planes (8 consecutive rows of one column) IS the B
+// operand of v_mfma_f32_16x16x32_bf16 -- no conversion, no split, no zero-plane test; tile j of a 64-column group is columns 16 j .. 16 j + 15
+// (contiguous, not interleaved as in the float32 layout); two stages of X in flight per wave (16 or 32 registers each).  Products per accumulator:
+// p0 x0, p1 x0, p2 x0 (NPX = 2: then p0 x1, p1 x1): the terms with xp + pp <= 2, as in stream_gemm_bf16_kernel; float32-grade, not bitwise that
+// kernel's (another matrix instruction).  Panel staging, stream-K division, teams, pieces: x3v's.
+template <int KT, int M16A, int NPX>
+__global__ __launch_bounds__(512, 1)
+void stream_gemm_bf16v_kernel(const unsigned short* __restrict__ S, int64_t x_plane, const float* __restrict__ Pf, float* __restrict__ pieces,
+                              SweepGeom g, int* __restrict__ xcc_out)
+{
+    sg_report_xcc(xcc_out);
+    static_assert(M16A >= 1 && M16A <= 2 * KT && M16A <= 8, "active 16-component tiles");
+    static_assert(NPX == 1 || NPX == 2, "planes of X");
+    constexpr int KP = 32 * KT, M16 = 2 * KT, KPA = 16 * M16A;
+    constexpr int WAVE_F = 64, NW = 8, BLOCK_F = NW * WAVE_F;
+    constexpr int NT = 64 * NW;
+    constexpr int ROWS = 32;
+    static_assert(SG_ROW_ALIGN % (2 * ROWS) == 0, "stream-K spans hold an even number of stages");
+    constexpr int STAGE_BF16 = ROWS * KP;
+    constexpr int SETS = (ROWS / 8) * KP;
+    static_assert(SETS <= NT, "one 8-row set of the panel per thread and stage");
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * STAGE_BF16];
+    __shared__ __attribute__((aligned(16))) float flush_tr[NW][16 * (KP + 4)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kg = lane >> 4;
+    SgWalk walk;
+    int team, member;
+    sg_team_of_block(g, blockIdx.x, team, member);
+    sg_walk_init(walk, g, team);
+
+    const int p_set = tid % SETS;                         // (every thread loads a set: see stream_gemm_x3v_kernel)
+    const int p_rb = p_set / KP, p_col = p_set % KP;
+    const bool p_mine = tid < SETS && p_col < KPA;
+    float pf[8];
+    u32x4 x[2][NPX][4];                                   // ring slot = stage parity: [slot][plane][16-column tile]
+
+    int ft, r_begin, r_end;
+    int64_t slot;
+    while (sg_walk_next(walk, g, ft, r_begin, r_end, slot)) {
+        const int nst = (r_end - r_begin) / ROWS;          // even (SG_ROW_ALIGN = 64 rows)
+        const int wt = ft * g.gw + member;
+        if ((int64_t)wt * BLOCK_F >= g.F) continue;
+        const int f0 = wt * BLOCK_F + wave * WAVE_F;
+        const bool active = f0 < g.F;
+
+        const float* pfptr = Pf + (int64_t)(r_begin + 8 * p_rb) * KP + p_col;
+        auto load_p = [&](int t) {
+            const float* src = pfptr + (int64_t)t * ROWS * KP;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = src[e * KP];
+        };
+        auto store_p = [&](int b) {
+            if (p_mine) {
+                u32x4 o[3];
+                x3_split8_scalar(pf, o);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(&lds[b][q * STAGE_BF16 + 8 * p_set]) = o[q];
+            }
+        };
+
+        __syncthreads();
+        load_p(0);
+        store_p(0);
+        load_p(1);                                         // (nst >= 2)
+
+        if (!active) {
+            __syncthreads();
+            for (int t = 0; t + 1 < nst; ++t) {
+                store_p((t + 1) & 1);
+                if (t + 2 < nst) load_p(t + 2);
+                __syncthreads();
+            }
+            continue;
+        }
+
+        f32x4 acc[M16A][4];
+#pragma unroll
+        for (int m = 0; m < M16A; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // granule (row block r_begin / 8 + 4 t + kg, column f0 + 16 j + c16) of plane xp: wave-uniform base + one 32-bit lane offset
+        // (bytes: 16 per granule; the lane's part (kg F + c16) 16 < 2^32 for F <= 2^26 -- the host keeps longer axes on the 4-wave kernel)
+        const char* xbase = reinterpret_cast<const char*>(S) + ((int64_t)(r_begin / 8) * g.F + f0) * 16;
+        const unsigned x_lane = (unsigned)(((int64_t)kg * g.F + c16) * 16);
+        auto load_x = [&](int t, auto slot_c) {
+            constexpr int XS = decltype(slot_c)::value;
+#pragma unroll
+            for (int xp = 0; xp < NPX; ++xp)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    x[XS][xp][j] = sg_load_nt_saddr<u32x4>(xbase + ((int64_t)(4 * t) * g.F + 16 * j) * 16 + xp * x_plane * 2, x_lane);
+        };
+        using Slot0 = std::integral_constant<int, 0>;
+        using Slot1 = std::integral_constant<int, 1>;
+        const int lds_lane = (kg * KP + c16) * 8;
+
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(0, Slot0{});
+        load_x(1, Slot1{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+
+        // one stage: the slot's granules are the B operands; component tile by component tile 3 ds_read_b128 (one tile ahead) and 12 (NPX = 2: 20)
+        // MFMAs; the slot is re-issued for stage t + 2 right after its last use
+        auto stage = [&](auto slot_c, const unsigned short* __restrict__ lrow, int t_next, bool last) {
+            constexpr int XS = decltype(slot_c)::value;
+            auto lda = [&](int m, u32x4 (&a)[3]) {
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) a[pp] = *reinterpret_cast<const u32x4*>(lrow + pp * STAGE_BF16 + (16 * m) * 8);
+            };
+            u32x4 a[2][3];
+            lda(0, a[0]);
+#pragma unroll
+            for (int m = 0; m < M16A; ++m) {
+                asm volatile("" ::: "memory");
+                if (m + 1 < M16A) lda(m + 1, a[(m + 1) & 1]);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int xp = 0; xp < NPX; ++xp) {
+                        if (xp + pp > 2) continue;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m & 1][pp]), __builtin_bit_cast(bf16x8, x[XS][xp][j]), acc[m][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!last) load_x(t_next, slot_c);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        int t = 0;
+        for (; t + 2 < nst; t += 2) {
+            store_p(1);
+            load_p(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(Slot0{}, &lds[0][lds_lane], t + 2, false);
+            __syncthreads();
+            store_p(0);
+            load_p(t + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(Slot1{}, &lds[1][lds_lane], t + 3, false);
+            __syncthreads();
+        }
+        store_p(1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(Slot0{}, &lds[0][lds_lane], 0, true);
+        __syncthreads();
+        stage(Slot1{}, &lds[1][lds_lane], 0, true);
+
+        // D: component = 16 m + 4 kg + e, column = c16 of tile j -> f_local = WAVE_F * wave + 16 j + c16 (contiguous tiles: row stride KP)
+        float* out = pieces + (slot * g.bf + member * BLOCK_F + wave * WAVE_F) * KP;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 d[M16];
+#pragma unroll
+            for (int m = 0; m < M16; ++m) d[m] = m < M16A ? acc[m < M16A ? m : 0][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            sg_flush_tile16<KT>(flush_tr[wave], d, out + (int64_t)(16 * j) * KP, KP, lane);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
 // One pass over X for 128 < K <= 256 ("x3w2", round 4).  The blocked two-half path of kernels_wide.hpp ran every sweep TWICE, once per
 // half of the components (X read four times per iteration: 0.32 of the HBM roof at K = 150).  Here a wave owns 64 columns x ALL 256
 // components -- 16 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 256 registers -- and a workgroup 256 columns, so X is read
